@@ -1,0 +1,235 @@
+"""Known-answer tests that pin the CPU oracle (the reference has no golden
+vectors, so these are closed forms plus the libstdc++ RNG draws recorded in SURVEY.md section 0.4)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from mvskit_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_minstd_draws_match_survey():
+    # propagate.cpp:139-140: default_random_engine + uniform_real_distribution<float>(-0.5, 0.5)
+    gold = json.load(open(os.path.join(GOLD, "rng_minstd_rand0.json")))["draws"]
+    out = np.zeros(4, np.float32)
+    ob.lib().orc_minstd_draws(4, out.ctypes.data)
+    np.testing.assert_allclose(out, np.asarray(gold, np.float32), rtol=0, atol=1e-9)
+
+
+def test_robustincc_inverse():
+    L = ob.lib()
+    for r in np.linspace(0.0, 0.3, 31):
+        assert abs(L.orc_robustincc(L.orc_unrobustincc(float(r))) - r) < 1e-6
+    assert L.orc_robustincc(0.0) == 0.0
+    assert abs(L.orc_robustincc(1.0) - 0.25) < 1e-7  # optim.cpp:622-624: c/(1+3c)
+
+
+def test_libm_subset_accuracy():
+    L = ob.lib()
+    xs = np.linspace(-math.pi / 2, math.pi / 2, 2001).astype(np.float32)
+    assert max(abs(L.orc_sinf(float(x)) - math.sin(float(x))) for x in xs) < 3e-7
+    assert max(abs(L.orc_cosf(float(x)) - math.cos(float(x))) for x in xs) < 3e-7
+    us = np.linspace(-1, 1, 2001).astype(np.float32)
+    assert max(abs(L.orc_asinf(float(u)) - math.asin(float(u))) for u in us) < 6e-7
+    assert max(abs(L.orc_acosf(float(u)) - math.acos(float(u))) for u in us) < 1e-6
+    ts = np.linspace(-20, 20, 2001).astype(np.float32)
+    assert max(abs(L.orc_atanf(float(t)) - math.atan(float(t))) for t in ts) < 3e-7
+
+
+def test_counter_rng_range_and_determinism():
+    L = ob.lib()
+    v = np.array([L.orc_rng_uniform(7, i, 1, 2, 3, 4) for i in range(4096)])
+    assert v.min() >= -0.5 and v.max() < 0.5
+    assert abs(v.mean()) < 0.02 and abs(v.std() - 1 / math.sqrt(12)) < 0.01
+    assert L.orc_rng_uniform(7, 5, 1, 2, 3, 4) == L.orc_rng_uniform(7, 5, 1, 2, 3, 4)
+    gold = json.load(open(os.path.join(GOLD, "rng_counter.json")))
+    for k, val in zip(gold["keys"], gold["values"]):
+        assert L.orc_rng_uniform(*k) == np.float32(val)
+
+
+def _fronto_scene(W=96, H=80, value=None, seed=3):
+    """Two identical cameras looking straight down -z at the plane z = 0 from z = 4."""
+    rng = np.random.RandomState(seed)
+    f = 100.0
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1.0]])
+    R = np.diag([1.0, -1.0, -1.0])  # x right, y down, z forward = -z world
+    t = -R @ np.array([0, 0, 4.0])
+    P = (K @ np.concatenate([R, t[:, None]], 1)).astype(np.float32)
+    img = rng.randint(0, 256, size=(H, W, 3)).astype(np.uint8) if value is None else np.full((H, W, 3), value, np.uint8)
+    return synth.Scene(W=W, H=H, P=np.stack([P, P]), images=np.stack([img, img]), centers=np.zeros((2, 3)))
+
+
+def test_project_unproject_roundtrip():
+    sc = _fronto_scene()
+    o = ob.Oracle(2, level=0, minImageNum=2)
+    o.set_scene(sc)
+    for (u, v, d) in [(10.0, 20.0, 4.0), (50.5, 33.25, 3.0), (80.0, 70.0, 7.5)]:
+        X = o.unproject(0, (u * d, v * d, d), 0)
+        ic = o.project(0, X, 0)
+        np.testing.assert_allclose(ic, [u, v, 1.0], rtol=0, atol=2e-4)
+    # behind the camera: camera.cpp:313-316
+    np.testing.assert_array_equal(o.project(0, (0, 0, 5.0, 1), 0), [-65535.0, -65535.0, -1.0])
+    # level l halves rows 0,1: camera.cpp:95-99
+    a, b = o.project(0, (0.3, 0.2, 0, 1), 0), o.project(0, (0.3, 0.2, 0, 1), 1)
+    np.testing.assert_allclose(b[:2], a[:2] / 2, rtol=1e-6)
+
+
+def test_pyramid_constant_image_has_dark_border():
+    # image.cpp:245-315: out-of-range taps are dropped without renormalising (defect D8)
+    sc = _fronto_scene(value=200)
+    o = ob.Oracle(2, level=0, minImageNum=2)
+    o.set_scene(sc)
+    l1 = o.pyramid(0, 1)
+    assert l1.shape == (40, 48, 3)
+    assert (l1[1:-1, 1:-1] == 200).all()
+    assert (l1[0, 1:-1] == int(math.floor(200 * 7 / 8 + 0.5))).all()      # one tap row of weight 1/8 missing
+    assert (l1[1:-1, 0] == int(math.floor(200 * 7 / 8 + 0.5))).all()
+    assert l1[0, 0, 0] == int(math.floor(200 * 49 / 64 + 0.5))
+    # the last row/column loses its tap 2y+2 = H as well, so both borders are dark
+    assert (l1[-1, 1:-1] == 175).all() and (l1[1:-1, -1] == 175).all()
+
+
+def test_pyramid_matches_numpy_restatement(small_plane_scene):
+    o = ob.Oracle(3, level=0, minImageNum=2)
+    o.set_scene(small_plane_scene)
+    src = small_plane_scene.images[1].astype(np.float32)
+    H, W = src.shape[:2]
+    k = np.array([1, 3, 3, 1], np.float32)
+    mask = np.outer(k, k) / 64.0
+    pad = np.zeros((H + 3, W + 3, 3), np.float32)
+    pad[1:H + 1, 1:W + 1] = src
+    out = np.zeros((H // 2, W // 2, 3), np.float32)
+    for i in range(4):
+        for j in range(4):
+            out += mask[i, j] * pad[i:i + H:2, j:j + W:2][: H // 2, : W // 2]
+    exp = np.floor(out + 0.5).astype(np.uint8)
+    got = o.pyramid(1, 1)
+    assert (np.abs(got.astype(int) - exp.astype(int)) <= 1).all()  # summation order may differ by 1 ulp at .5
+    assert (got == exp).mean() > 0.999
+
+
+def test_fronto_parallel_tex_is_integer_pixel_window():
+    # optim.cpp:80-83 scales the patch axes to one pixel per step, so for a fronto-parallel patch whose
+    # centre projects to an integer pixel getTex returns the 7x7 window of raw pixels (image.cpp:447-472)
+    sc = _fronto_scene()
+    o = ob.Oracle(2, level=0, minImageNum=2)
+    o.set_scene(sc)
+    u, v = 40, 30
+    X = o.unproject(0, (u * 4.0, v * 4.0, 4.0), 0)
+    n = (0, 0, 1, 0)
+    px, py = o.get_paxes(0, X, n)
+    flag, tex = o.get_tex(X, px, py, n, 0)
+    assert flag == 0
+    win = sc.images[0][v - 3:v + 4, u - 3:u + 4].reshape(49, 3).astype(np.float32)
+    # patch y axis = n x camera-x: image rows may run in either direction, columns likewise
+    cands = [win, win.reshape(7, 7, 3)[::-1].reshape(49, 3), win.reshape(7, 7, 3)[:, ::-1].reshape(49, 3),
+             win.reshape(7, 7, 3)[::-1, ::-1].reshape(49, 3)]
+    err = min(np.abs(tex - c).max() for c in cands)
+    assert err < 0.05, err
+
+
+def test_bilinear_formula():
+    sc = _fronto_scene()
+    o = ob.Oracle(2, level=0, minImageNum=2)
+    o.set_scene(sc)
+    img = sc.images[0].astype(np.float64)
+    for (x, y) in [(10.25, 20.75), (33.0, 12.5), (50.9, 60.1)]:
+        lx, ly = int(x), int(y)
+        dx, dy = x - lx, y - ly
+        exp = (img[ly, lx] * (1 - dx) * (1 - dy) + img[ly + 1, lx] * (1 - dx) * dy + img[ly, lx + 1] * dx * (1 - dy)
+               + img[ly + 1, lx + 1] * dx * dy)
+        np.testing.assert_allclose(o.get_color(0, x, y, 0), exp, rtol=1e-5, atol=1e-3)
+
+
+def _patch(coord, normal, images):
+    r = np.zeros(1, dtype=ob.PATCH_DTYPE)[0]
+    r["coord"] = coord
+    r["normal"] = normal
+    r["ncc"] = -1
+    r["nimages"] = len(images)
+    r["images"][: len(images)] = images
+    r["flags"] = 1
+    return r
+
+
+def test_identical_views_give_zero_incc_and_constant_gives_dot_zero():
+    sc = _fronto_scene()
+    o = ob.Oracle(2, level=0, minImageNum=2)
+    o.set_scene(sc)
+    X = o.unproject(0, (40 * 4.0, 30 * 4.0, 4.0), 0)
+    p = _patch(X, (0, 0, 1, 0), [0, 1])
+    assert abs(o.compute_incc(p, robust=0)) < 1e-5       # identical textures: dot = 1 (optim.cpp:601-609)
+    assert abs(o.compute_ncc(p) - 1.0) < 1e-5
+    m = o.set_inccs_matrix(p, robust=1)
+    assert np.abs(m).max() < 1e-5
+    sc2 = _fronto_scene(value=77)
+    o2 = ob.Oracle(2, level=0, minImageNum=2)
+    o2.set_scene(sc2)
+    # constant texture: msd == 0 -> 1 (optim.cpp:934-936), normalised tex = 0, dot = 0, INCC = 1
+    assert abs(o2.compute_incc(p, robust=0) - 1.0) < 1e-6
+    flag, tex = o2.get_tex(X, *o2.get_paxes(0, X, (0, 0, 1, 0)), (0, 0, 1, 0), 0, normalize=True)
+    assert flag == 0 and np.abs(tex).max() == 0.0
+
+
+def test_tex_rejected_outside_cone_and_near_border():
+    sc = _fronto_scene()
+    o = ob.Oracle(2, level=0, minImageNum=2)
+    o.set_scene(sc)
+    X = o.unproject(0, (40 * 4.0, 30 * 4.0, 4.0), 0)
+    px, py = o.get_paxes(0, X, (0, 0, 1, 0))
+    n70 = (math.sin(math.radians(70)), 0, math.cos(math.radians(70)), 0)  # 70 deg > angleThreshold1 (optim.cpp:795-798)
+    assert o.get_tex(X, px, py, n70, 0)[0] == -1
+    Xb = o.unproject(0, (4.0 * 4.0, 30 * 4.0, 4.0), 0)  # window would reach x < margin2 (optim.cpp:908-912)
+    assert o.get_tex(Xb, px, py, (0, 0, 1, 0), 0)[0] == -1
+
+
+def test_encode_decode_identity(small_plane_scene):
+    o = ob.Oracle(3, level=0, minImageNum=2)
+    o.set_scene(small_plane_scene)
+    rng = np.random.RandomState(5)
+    for _ in range(20):
+        n = np.array([rng.normal() * 0.3, rng.normal() * 0.3, 1.0])
+        n /= np.linalg.norm(n)
+        p = _patch((rng.uniform(-0.5, 0.5), rng.uniform(-0.3, 0.3), 0.01, 1), (*n, 0), [1, 0, 2])
+        p["dscale"] = 0.01
+        x = o.encode(p)
+        assert x[0] == 0.0
+        c, nn = o.decode(p, x)
+        np.testing.assert_allclose(c, p["coord"], atol=1e-6)
+        # a1 = acos(-fz/cos a2) is ill-conditioned near 1 (optim.cpp:570-572): ~sqrt(eps) in the angle
+        np.testing.assert_allclose(nn[:3], n, atol=2e-4)
+        c2, _ = o.decode(p, (2.0, x[1], x[2]))  # depth moves along the reference ray by dscale*x0 (optim.cpp:597-599)
+        cam = o.camera(1)["center"]
+        ray = (p["coord"] - cam) / np.linalg.norm(p["coord"] - cam)
+        np.testing.assert_allclose(c2, p["coord"] + 0.02 * ray, atol=1e-6)
+
+
+def test_sum_modes_agree(small_plane_scene):
+    seeds = synth.make_seeds(small_plane_scene, stride=16)
+    a = ob.Oracle(3, level=0, minImageNum=2, sum_mode=ob.SUM_SEQ)
+    b = ob.Oracle(3, level=0, minImageNum=2, sum_mode=ob.SUM_TREE64)
+    a.set_scene(small_plane_scene)
+    b.set_scene(small_plane_scene)
+    d = [abs(a.compute_ncc(s) - b.compute_ncc(s)) for s in seeds[:50]]
+    assert max(d) < 1e-5
+
+
+def test_refinement_reduces_depth_error(small_plane_scene):
+    seeds = synth.make_seeds(small_plane_scene, stride=12, depth_noise=1.0, seed=11)
+    o = ob.Oracle(3, level=0, minImageNum=2)
+    o.set_scene(small_plane_scene)
+    before, after = [], []
+    for i, s in enumerate(seeds[:40]):
+        f, p = o.preprocess(s)
+        if f != 0:
+            continue
+        _, q = o.refine(p, (0, 0, i, 0))
+        before.append(abs(float(s["coord"][2])))
+        after.append(abs(float(q["coord"][2])))
+    assert len(before) > 20
+    assert np.median(after) < 0.35 * np.median(before)
