@@ -1,0 +1,173 @@
+/*
+ * mvskit_engine.h -- C ABI of the MI355X PatchMatch-MVS propagation/optimisation engine.
+ *
+ * This is the drop-in boundary for the hot path of imkaywu/MVSKit:
+ *     PmMvps::run  ->  Propagate::run(iter)                       pmmvps/pmmvps.cpp:95
+ *         -> propagatePmImage / propagatePatch / generatePatch    pmmvps/propagate.cpp:72-237
+ *         -> Optim::preProcess / refinePatch / postProcess        pmmvps/optim.cpp:137-547
+ *         -> PatchManager grid operations                         pmmvps/patch_manager.cpp:158-433
+ * The reference has no FFI: its boundary is the C++ object graph PmMvps owns by value
+ * (pmmvps/pmmvps.hpp:93-103).  A maintainer replaces the body of Propagate::run with calls to the
+ * entry points below (INTEGRATION.md shows the patch); mvskit_amd/host/ holds a host-side mirror
+ * of Option / PhotoSet / PatchManager / Propagate / PmMvps that does exactly that.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  Every call returns 0 on success
+ * and a negative mvs_status otherwise (never exit(); the reference exit(1)s, e.g.
+ * pmmvps/propagate.cpp:39-42).  Host buffers stay owned by the caller; the engine owns all device
+ * memory.  One host thread per handle.  All device work runs on one HIP stream per handle.
+ */
+#ifndef MVSKIT_ENGINE_H
+#define MVSKIT_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_MAX_IMAGES 32 /* storage of Patch::m_images / m_vimages in a record */
+#define MVS_LIST_CAP 16   /* lists are truncated to this many views (engine limit) */
+
+typedef enum mvs_status {
+    MVS_OK = 0,
+    MVS_ERR_ARG = -1,      /* bad argument / configuration */
+    MVS_ERR_STATE = -2,    /* call out of order (views not set, ...) */
+    MVS_ERR_HIP = -3,      /* HIP runtime error, see mvs_last_error() */
+    MVS_ERR_CAPACITY = -4, /* patch pool or staging capacity exceeded */
+    MVS_ERR_NO_DEVICE = -5
+} mvs_status;
+
+/* Patch record: pmmvps/patch.hpp:33-66.  coord.w = 1, normal.w = 0.  128 bytes. */
+typedef struct mvs_patch {
+    float coord[4];   /* Patch::m_coord */
+    float normal[4];  /* Patch::m_normal */
+    float ncc;        /* Patch::m_ncc; < 0 = not computed yet (patch.cpp:12) */
+    float dscale;     /* Patch::m_dscale */
+    float ascale;     /* Patch::m_ascale */
+    float tmp;        /* Patch::m_tmp */
+    int32_t nimages;  /* m_images.size() */
+    int32_t nvimages; /* m_vimages.size() */
+    int32_t flags;    /* bit 0: alive.  In exported "new" records bits 8.. hold the swept view */
+    int32_t id;       /* pool index (download) / destination cell (exported "new" records) */
+    uint8_t images[MVS_MAX_IMAGES];  /* Patch::m_images, [0] is the reference view */
+    uint8_t vimages[MVS_MAX_IMAGES]; /* Patch::m_vimages */
+} mvs_patch;
+
+/* Option (pmmvps/option.hpp:20-73) + the engine's own knobs. */
+typedef struct mvs_config {
+    int32_t nviews;          /* Option::m_nimages */
+    int32_t level;           /* Option::m_level */
+    int32_t csize;           /* Option::m_csize */
+    int32_t wsize;           /* Option::m_wsize (<= 8: one wavefront lane per sample) */
+    int32_t minImageNum;     /* Option::m_minImageNum */
+    int32_t max_propag;      /* Propagate::MAX_NUM_OF_PROPAG, propagate.cpp:24 */
+    float nccThreshold;      /* Option::m_nccThreshold */
+    float maxAngleThreshold; /* Option::m_maxAngleThreshold, radians */
+    float quadThreshold;     /* Option::m_quadThreshold */
+    int32_t depth;           /* PmMvps::m_depth when Propagate::run is entered */
+    uint32_t seed;           /* counter-based RNG seed */
+    int32_t refine_steps;    /* halving steps of the refiner; 1 + 3*steps cost evaluations */
+    float refine_rd0;        /* initial depth range in units of Patch::m_dscale */
+    float refine_ra0;        /* initial angle range in units of pi/48 (optim.cpp:487) */
+    int32_t enable_check;    /* Optim::check when depth >= 2 (optim.cpp:292) */
+    int32_t view_begin;      /* views view_begin, view_begin+view_stride, ... are swept by this engine */
+    int32_t view_stride;
+    int32_t device;          /* HIP device ordinal */
+    int64_t max_patches;     /* patch pool capacity (0 = 4 * total cells) */
+} mvs_config;
+
+/* One view: PhotoSet::m_photos[i] (image/photoSet.hpp:62).  P is the row-major 3x4 level-0 projection
+ * (`CONTOUR` camera text, image/camera.cpp:110-116); rgb is the level-0 image as Image::m_images[0]
+ * holds it, interleaved uint8 RGB, H rows of W pixels (image/image.hpp:76); mask is H*W uint8 or NULL. */
+typedef struct mvs_view_desc {
+    int32_t width, height;
+    float P[12];
+    const uint8_t* rgb;
+    const uint8_t* mask;
+} mvs_view_desc;
+
+/* Propagate's counters (pmmvps/propagate.hpp:63-69) plus work counts for the metric. */
+typedef struct mvs_counters {
+    int64_t candidates;  /* generatePatch returned a patch */
+    int64_t prefiltered; /* cand.ncc < worst.ncc, propagate.cpp:170 */
+    int64_t patches;     /* reached Optim::preProcess, propagate.cpp:182 -- the unit of "patches/s" */
+    int64_t fail0;       /* m_fcount0 */
+    int64_t fail1;       /* m_fcount1 */
+    int64_t inserted;    /* pcount */
+    int64_t replaced;    /* rcount */
+    int64_t evals;       /* texture evaluations (one getPAxes + up to V getTex) */
+    int64_t view_evals;  /* getTex calls that sampled: 588 algorithmic bytes each */
+    int64_t trimmed;     /* removed by the MAX_NUM_OF_PATCHES trim */
+} mvs_counters;
+
+typedef struct mvs_engine mvs_engine;
+
+const char* mvs_last_error(void);
+int mvs_device_count(void);
+void mvs_default_config(mvs_config* cfg); /* Option::Option, option.cpp:19-33 */
+
+/* PmMvps::init (pmmvps.cpp:18-68): thresholds, tau = min(2*minImageNum, nviews), maxLevel = level+3 */
+int mvs_engine_create(const mvs_config* cfg, mvs_engine** out);
+int mvs_engine_destroy(mvs_engine* e);
+
+/* PhotoSet::init + Image::buildImagePyramid + Camera::updateCamera + Optim::setAxesScales +
+ * PatchManager::init: uploads level 0, builds pyramids, cameras and grids on the device. */
+int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views);
+int mvs_engine_grid_dims(mvs_engine* e, int view, int* gw, int* gh); /* patch_manager.cpp:36-37 */
+int mvs_engine_get_pyramid(mvs_engine* e, int view, int level, uint8_t* rgb_out, int* W, int* H);
+
+/* thresholds: PmMvps::m_nccThreshold, m_nccThresholdBefore, m_depth */
+int mvs_engine_set_thresholds(mvs_engine* e, float nccThreshold, float nccThresholdBefore, int depth);
+int mvs_engine_get_thresholds(mvs_engine* e, float* nccThreshold, float* nccThresholdBefore, int* depth);
+int mvs_engine_update_threshold(mvs_engine* e); /* PmMvps::updateThreshold + ++m_depth, pmmvps.cpp:70-74,105 */
+
+/* PatchManager::readPatches tail (patch_manager.cpp:450-463): seeds -> pool */
+int mvs_engine_upload_patches(mvs_engine* e, int64_t n, const mvs_patch* patches);
+int mvs_engine_clear_patches(mvs_engine* e);
+int mvs_engine_num_patches(mvs_engine* e, int64_t* n_alive);
+int mvs_engine_download_patches(mvs_engine* e, int64_t cap, mvs_patch* out, int64_t* n); /* collectPatches */
+
+/* Propagate::run(iter), propagate.cpp:28-64: two colour passes, each = index build + sweep + commit */
+int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out);
+
+/* The same split for view-sharded runs: every rank holds the whole pool, sweeps its own views
+ * (view_begin/view_stride) and exchanges what it created before every rank commits the union. */
+int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out); /* index build + sweep */
+int mvs_engine_export_counts(mvs_engine* e, int64_t* n_new, int64_t* n_kill, int32_t* per_view_new /* [nviews] */);
+/* device buffers owned by the caller (e.g. torch tensors): records ordered (view, cell, sequence) */
+int mvs_engine_export_device(mvs_engine* e, void* d_new_records, int64_t cap_new, void* d_kill_ids, int64_t cap_kill);
+int mvs_engine_commit_device(mvs_engine* e, const void* d_new_records, int64_t n_new, const void* d_kill_ids, int64_t n_kill);
+int mvs_engine_commit_local(mvs_engine* e);
+
+/* parity artefact: kind 0 = m_dpgrids patch, kind 1 = best-NCC patch of
+ * m_pgrids[view][cell] whose reference view is `view`.  depth[gw*gh] = oaxis.coord, normal[gw*gh*3],
+ * ids[gw*gh]; empty cells are NaN / -1.  Host buffers. */
+int mvs_engine_depth_normal_map(mvs_engine* e, int view, int kind, float* depth, float* normal, int32_t* ids);
+
+/* Batched single functions of the path, for parity tests and kernel benchmarks.
+ * op: see mvs_probe_op.  in/out are host arrays of n records / values. */
+typedef enum mvs_probe_op {
+    MVS_PROBE_NCC = 0,        /* PatchManager::computeNcc      -> out_f[n] */
+    MVS_PROBE_PREPROCESS = 1, /* Optim::preProcess             -> out_rec[n], out_i[n] = flag */
+    MVS_PROBE_REFINE = 2,     /* Optim::refinePatch            -> out_rec[n]; key = (0,0,i,0) */
+    MVS_PROBE_POSTPROCESS = 3,/* Optim::postProcess            -> out_rec[n], out_i[n] = flag */
+    MVS_PROBE_COST = 4,       /* Optim::cost_func at encode(p) -> out_f[n] */
+    MVS_PROBE_MATH = 5        /* in_f[n] -> out_f[5n]: sin, cos, asin, acos, atan of each input */
+} mvs_probe_op;
+int mvs_engine_probe(mvs_engine* e, int op, int64_t n, const mvs_patch* in_rec, const float* in_f,
+                     mvs_patch* out_rec, float* out_f, int32_t* out_i);
+
+/* timing of the last mvs_engine_pass / mvs_engine_propagate, measured with HIP events on the engine's stream */
+typedef struct mvs_timing {
+    float index_ms;  /* index build (CSR, trim, depth maps) */
+    float sweep_ms;  /* the sweep kernel(s) */
+    float commit_ms; /* commit */
+    int32_t sweep_launches;
+} mvs_timing;
+int mvs_engine_last_timing(mvs_engine* e, mvs_timing* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVSKIT_ENGINE_H */

@@ -1,0 +1,46 @@
+"""Builds the engine's shared library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmvskit_engine.so")
+SOURCES = ["mvs_kernels.hip", "mvs_engine.cpp"]
+DEPS = SOURCES + ["mvs_device.cuh", "mvs_types.h", "mvs_kernels.h", os.path.join(ROOT, "include", "mvskit_engine.h")]
+
+# -ffp-contract=off: the explicit fmaf chains in the source are the only fused operations (DESIGN.md,
+# "engine arithmetic"), which is what lets the CPU oracle reproduce the results bit for bit.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-Wno-implicit-const-int-float-conversion"]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for d in DEPS:
+        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        if os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build_engine(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_engine(force=True, verbose=True))

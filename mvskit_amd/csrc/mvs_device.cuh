@@ -1,0 +1,811 @@
+// mvs_device.cuh -- device functions of the PatchMatch-MVS engine for gfx950 (wave64).
+//
+// Execution model: ONE 64-lane wavefront works on one patch / one destination cell.  Control flow is
+// wave-uniform.  Two lane layouts coexist in registers:
+//   * sample lanes: lane i < wsize*wsize holds sample i of the 7x7 texture window (optim.cpp:835-842);
+//     channel sums, the ssd and the NCC dot product are wave butterflies (DPP), offsets 1,2,4,8,16,32;
+//   * view lanes: lane j holds element j of a per-view array (Patch::m_images[j], its projection frame,
+//     its ray, unit, INCC ...), read back with v_readlane when a loop needs element j uniformly.
+// Arithmetic follows the conventions stated in DESIGN.md ("engine arithmetic"): fp32, no implicit
+// contraction (-ffp-contract=off), dot products as left-to-right fmaf chains, own polynomial
+// sin/cos/asin/acos/atan -- the same operation order the CPU oracle's TREE64 mode uses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include "mvs_types.h"
+
+namespace mvsdev {
+
+struct F3 { float x, y, z; };
+struct F4 { float x, y, z, w; };
+
+#define DEV __device__ __forceinline__
+
+DEV int lane_id() { return (int)(threadIdx.x & 63u); }
+DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DEV int rli(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+DEV float rlf(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+DEV int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+DEV unsigned long long ballot(bool p) { return __ballot(p); }
+
+DEV float dot4(F4 a, F4 b) { return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x))); }
+DEV float dot3(F3 a, F3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+DEV float norm4(F4 a) { return sqrtf(dot4(a, a)); }
+DEV float norm3(F3 a) { return sqrtf(dot3(a, a)); }
+DEV F4 sub4(F4 a, F4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+DEV F4 add4(F4 a, F4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+DEV F4 mul4(F4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+DEV F4 div4(F4 a, float s) { return {a.x / s, a.y / s, a.z / s, a.w / s}; }
+DEV F3 sub3(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV F3 div3(F3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+DEV F3 cross3(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DEV F4 ld4(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+DEV F3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+
+// ------------------------------------------------------------------ wave butterflies
+// sum over the 64 lanes, pairing order 1,2,4,8,16,32; every lane ends with the same bits.
+template <int CTRL> DEV float dpp_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+DEV float wave_sum(float x) {
+    x = x + dpp_f<0xB1>(x);   // quad_perm [1,0,3,2]   : i ^ 1
+    x = x + dpp_f<0x4E>(x);   // quad_perm [2,3,0,1]   : i ^ 2
+    x = x + dpp_f<0x141>(x);  // row_half_mirror       : other quad of the 8 (== i ^ 4 once quads are uniform)
+    x = x + dpp_f<0x140>(x);  // row_mirror            : other half of the row of 16 (== i ^ 8)
+    x = x + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));  // i ^ 16
+    return rlf(x, 0) + rlf(x, 32);                                                    // i ^ 32
+}
+DEV float wave_min(float x) {
+    x = fminf(x, dpp_f<0xB1>(x));
+    x = fminf(x, dpp_f<0x4E>(x));
+    x = fminf(x, dpp_f<0x141>(x));
+    x = fminf(x, dpp_f<0x140>(x));
+    x = fminf(x, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F)));
+    return fminf(rlf(x, 0), rlf(x, 32));
+}
+
+// ------------------------------------------------------------------ deterministic libm subset
+// (same kernels, constants and evaluation order as the oracle's pm_* functions)
+#define MVS_PIO2_HI 1.57079625129699707031f
+#define MVS_PIO2_LO 7.54978941586159635335e-08f
+#define MVS_PIO4 0.78539816339744830962f
+#define MVS_PI 3.14159265358979323846f
+DEV float k_sinf(float x) {
+    float z = x * x;
+    float p = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    p = p * z - 1.6666654611e-1f;
+    return x + x * z * p;
+}
+DEV float k_cosf(float x) {
+    float z = x * x;
+    float p = 2.443315711809948e-5f * z - 1.388731625493765e-3f;
+    p = p * z + 4.166664568298827e-2f;
+    return (1.0f - 0.5f * z) + z * z * p;
+}
+DEV float pm_sinf(float x) {
+    float a = fabsf(x), r;
+    if (a <= MVS_PIO4) r = k_sinf(a);
+    else if (a <= 3.0f * MVS_PIO4) r = k_cosf((MVS_PIO2_HI - a) + MVS_PIO2_LO);
+    else r = k_sinf(MVS_PI - a);
+    return x < 0.0f ? -r : r;
+}
+DEV float pm_cosf(float x) {
+    float a = fabsf(x);
+    if (a <= MVS_PIO4) return k_cosf(a);
+    if (a <= 3.0f * MVS_PIO4) return k_sinf((MVS_PIO2_HI - a) + MVS_PIO2_LO);
+    return -k_cosf(MVS_PI - a);
+}
+DEV float pm_asinf(float x) {
+    float a = fabsf(x);
+    if (a > 1.0f) a = 1.0f;
+    float z, xx;
+    bool flag = a > 0.5f;
+    if (flag) { z = 0.5f * (1.0f - a); xx = sqrtf(z); }
+    else { z = a * a; xx = a; }
+    float p = 4.2163199048e-2f * z + 2.4181311049e-2f;
+    p = p * z + 4.5470025998e-2f;
+    p = p * z + 7.4953002686e-2f;
+    p = p * z + 1.6666752422e-1f;
+    float r = p * z * xx + xx;
+    if (flag) { r = r + r; r = (MVS_PIO2_HI - r) + MVS_PIO2_LO; }
+    return x < 0.0f ? -r : r;
+}
+DEV float pm_acosf(float x) {
+    if (x < -0.5f) return MVS_PI - 2.0f * pm_asinf(sqrtf(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * pm_asinf(sqrtf(0.5f * (1.0f - x)));
+    return MVS_PIO2_HI - pm_asinf(x);
+}
+DEV float pm_atanf(float v) {
+    float x = fabsf(v), y;
+    if (x > 2.414213562373095f) { y = MVS_PIO2_HI; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = MVS_PIO4; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    float p = 8.05374449538e-2f * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    y = y + (p * z * x + x);
+    return v < 0.0f ? -y : y;
+}
+
+// ------------------------------------------------------------------ counter-based RNG
+DEV uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+DEV float rng_uniform(uint32_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e) {
+    uint32_t h = mix32(seed ^ 0x9e3779b9u);
+    h = mix32(h ^ a) + 0x85ebca6bu;
+    h = mix32(h ^ b) + 0xc2b2ae35u;
+    h = mix32(h ^ c) + 0x27d4eb2fu;
+    h = mix32(h ^ d) + 0x165667b1u;
+    h = mix32(h ^ e);
+    return (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f;
+}
+
+// ------------------------------------------------------------------ camera (image/camera.cpp)
+// Camera::project, camera.cpp:310-326
+DEV F3 project(const DView* vw, F4 X, int level) {
+    const float* P = vw->P[level];
+    float r0 = fma_(P[3], X.w, fma_(P[2], X.z, fma_(P[1], X.y, P[0] * X.x)));
+    float r1 = fma_(P[7], X.w, fma_(P[6], X.z, fma_(P[5], X.y, P[4] * X.x)));
+    float r2 = fma_(P[11], X.w, fma_(P[10], X.z, fma_(P[9], X.y, P[8] * X.x)));
+    if (r2 <= 0.0f) return {-65535.0f, -65535.0f, -1.0f};
+    const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
+    F3 ic{r0 / r2, r1 / r2, 1.0f};
+    ic.x = fmaxf(lo, fminf(hi, ic.x));
+    ic.y = fmaxf(lo, fminf(hi, ic.y));
+    return ic;
+}
+// Camera::unproject at m_level, camera.cpp:329-337
+DEV F4 unproject(const DView* vw, F3 ic, int level) {
+    const float* P = vw->P[level];
+    const float* M = vw->Minv;
+    F3 b{ic.x - P[3], ic.y - P[7], ic.z - P[11]};
+    return {fma_(M[2], b.z, fma_(M[1], b.y, M[0] * b.x)), fma_(M[5], b.z, fma_(M[4], b.y, M[3] * b.x)),
+            fma_(M[8], b.z, fma_(M[7], b.y, M[6] * b.x)), 1.0f};
+}
+// Optim::getUnit, optim.cpp:34-41 (double expression)
+DEV float get_unit(const DParams& prm, const DView* vw, F4 coord) {
+    const float fz = norm4(sub4(coord, ld4(vw->center)));
+    const float ips = vw->ipscale;
+    if (ips == 0.0f) return 1.0f;
+    return (float)(2.0 * (double)fz * (double)(1 << prm.level) / (double)ips);
+}
+// PatchManager::setGrids cell rule, patch_manager.cpp:241-250
+DEV void cell_of(const DParams& prm, const DView* vw, F4 coord, int& ix, int& iy) {
+    const F3 ic = project(vw, coord, prm.level);
+    ix = ((int)floorf(ic.x + 0.5f)) / prm.csize;
+    iy = ((int)floorf(ic.y + 0.5f)) / prm.csize;
+}
+// Optim::getPAxes, optim.cpp:67-84
+DEV void get_paxes(const DParams& prm, const DView* vw, F4 coord, F4 normal, F4& px, F4& py) {
+    const float pscale = get_unit(prm, vw, coord);
+    F3 n3{normal.x, normal.y, normal.z};
+    F3 y3 = cross3(n3, ld3(vw->xaxis));
+    y3 = div3(y3, norm3(y3));
+    F3 x3 = cross3(y3, n3);
+    px = {x3.x * pscale, x3.y * pscale, x3.z * pscale, 0.0f};
+    py = {y3.x * pscale, y3.y * pscale, y3.z * pscale, 0.0f};
+    const F3 c0 = project(vw, coord, prm.level);
+    const float xdis = norm3(sub3(project(vw, add4(coord, px), prm.level), c0));
+    const float ydis = norm3(sub3(project(vw, add4(coord, py), prm.level), c0));
+    px = div4(px, xdis);
+    py = div4(py, ydis);
+}
+DEV float robustincc(float incc) { return incc / (1 + 3 * incc); }
+DEV float unrobustincc(float r) { return r / (1 - 3 * r); }
+
+// ------------------------------------------------------------------ texture frames (view lanes)
+// Head of Optim::getTex, optim.cpp:790-818: per view the sampling frame (top-left, dx, dy, level).
+struct Frame {
+    float tlx, tly, dxx, dxy, dyx, dyy;
+    int lvl_ok;  // level | ok << 8
+};
+DEV int level_diff(const DParams& prm, float ratio) {
+    int ld = -4;
+    if (ratio >= 0.088388347648318f) ld = -3;
+    if (ratio >= 0.176776695296637f) ld = -2;
+    if (ratio >= 0.353553390593274f) ld = -1;
+    if (ratio >= 0.707106781186548f) ld = 0;
+    if (ratio >= 1.414213562373095f) ld = 1;
+    if (ratio >= 2.828427124746190f) ld = 2;
+    return max(-prm.level, min(2, ld));
+}
+DEV float pow2_level(int ld) { return __int_as_float((127 + ld) << 23); }  // Optim::myPow2, exact powers of two
+DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, bool active) {
+    Frame f{0, 0, 0, 0, 0, 0, 0};
+    if (!active) return f;
+    const DView* vw = prm.views + v;
+    F4 ray = sub4(ld4(vw->center), coord);
+    ray = div4(ray, norm4(ray));
+    const float weight = fmaxf(0.0f, dot4(ray, pz));
+    if (weight < prm.cosAngle1) return f;
+    F3 center = project(vw, coord, prm.level);
+    F3 dx = sub3(project(vw, add4(coord, px), prm.level), center);
+    F3 dy = sub3(project(vw, add4(coord, py), prm.level), center);
+    const float ratio = (norm3(dx) + norm3(dy)) / 2.0f;
+    const int ld = level_diff(prm, ratio);
+    const float scale = pow2_level(ld);
+    const int newLevel = prm.level + ld;
+    center = div3(center, scale);
+    dx = div3(dx, scale);
+    dy = div3(dy, scale);
+    // Optim::getTexSafe, optim.cpp:895-915
+    const float m = (float)(prm.wsize / 2);
+    const float tlx = (center.x - dx.x * m) - dy.x * m, trx = (center.x + dx.x * m) - dy.x * m;
+    const float blx = (center.x - dx.x * m) + dy.x * m, brx = (center.x + dx.x * m) + dy.x * m;
+    const float tly = (center.y - dx.y * m) - dy.y * m, try_ = (center.y + dx.y * m) - dy.y * m;
+    const float bly = (center.y - dx.y * m) + dy.y * m, bry = (center.y + dx.y * m) + dy.y * m;
+    const float minx = fminf(tlx, fminf(trx, fminf(blx, brx))), maxx = fmaxf(tlx, fmaxf(trx, fmaxf(blx, brx)));
+    const float miny = fminf(tly, fminf(try_, fminf(bly, bry))), maxy = fmaxf(tly, fmaxf(try_, fmaxf(bly, bry)));
+    const int margin2 = 2;
+    if (minx < margin2 || vw->W[newLevel] - 1 - margin2 <= maxx || miny < margin2 || vw->H[newLevel] - 1 - margin2 <= maxy) return f;
+    f.tlx = tlx; f.tly = tly; f.dxx = dx.x; f.dxy = dx.y; f.dyx = dy.x; f.dyy = dy.y;
+    f.lvl_ok = newLevel | (1 << 8);
+    return f;
+}
+
+struct __attribute__((packed, aligned(4))) Texel2 { uint32_t a, b; };
+
+// Per-wave working state.
+struct WaveCtx {
+    int lane;
+    bool sample_lane;   // lane < wsize*wsize
+    float fx, fy;       // this lane's sample column / row
+    unsigned evals, view_evals;
+};
+
+// Tail of Optim::getTex (sampling, optim.cpp:835-842 -> Image::getColor bilinear, image.cpp:447-472)
+// followed by Optim::normalize (optim.cpp:917-940) for view-lane j of `f`.  Returns false when the view
+// was rejected.  Non-sample lanes return zeros.
+DEV bool tex_sample_norm(const DParams& prm, WaveCtx& wc, const Frame& f, int j, int vj, float& t0, float& t1, float& t2) {
+    const int lo = rli(f.lvl_ok, j);
+    if (!(lo >> 8)) return false;
+    const int level = lo & 255;
+    const float tlx = rlf(f.tlx, j), tly = rlf(f.tly, j), dxx = rlf(f.dxx, j), dxy = rlf(f.dxy, j), dyx = rlf(f.dyx, j), dyy = rlf(f.dyy, j);
+    const DView* vw = prm.views + vj;
+    const uint32_t* img = vw->img[level];
+    const int W = vw->W[level];
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    if (wc.sample_lane) {
+        const float sx = fma_(dyx, wc.fy, fma_(dxx, wc.fx, tlx));
+        const float sy = fma_(dyy, wc.fy, fma_(dxy, wc.fx, tly));
+        const int lx = (int)sx, ly = (int)sy;
+        const uint32_t* p0 = img + (size_t)ly * W + lx;
+        const Texel2 q0 = *reinterpret_cast<const Texel2*>(p0);
+        const Texel2 q1 = *reinterpret_cast<const Texel2*>(p0 + W);
+        const float dx1 = sx - (float)lx, dx0 = 1.0f - dx1, dy1 = sy - (float)ly, dy0 = 1.0f - dy1;
+        const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+        r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
+        g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
+        b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
+    }
+    wc.view_evals++;
+    const float sz = (float)prm.wsz;
+    const float a0 = wave_sum(r) / sz, a1 = wave_sum(g) / sz, a2 = wave_sum(b) / sz;
+    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+    if (wc.sample_lane) { d0 = r - a0; d1 = g - a1; d2 = b - a2; }
+    const float ssd = wave_sum(fma_(d2, d2, fma_(d1, d1, d0 * d0)));
+    float msd = sqrtf(ssd / (float)(3 * prm.wsz));
+    if (msd == 0.0f) msd = 1.0f;
+    const float inv = 1.0f / msd;
+    t0 = d0 * inv; t1 = d1 * inv; t2 = d2 * inv;
+    return true;
+}
+// Optim::dot, optim.cpp:601-609
+DEV float tex_dot(const DParams& prm, float a0, float a1, float a2, float b0, float b1, float b2) {
+    return wave_sum(fma_(a2, b2, fma_(a1, b1, a0 * b0))) / (float)(3 * prm.wsz);
+}
+
+// ------------------------------------------------------------------ candidate patch (registers)
+// Uniform scalars plus view-lane arrays: lane j holds m_images[j], m_grids[j], m_vimages[j], m_vgrids[j].
+struct Cand {
+    F4 coord, normal;
+    float ncc, dscale, ascale, tmp;
+    int nimg, nvimg;
+    int img, gx, gy;     // view lanes
+    int vimg, vgx, vgy;  // view lanes
+};
+
+// Optim::computeUnits + computeWeights, optim.cpp:109-132, 942-948: returns the view-lane weight array
+DEV float compute_weights(const DParams& prm, const WaveCtx& wc, F4 coord, F4 normal, int img, int n) {
+    float unit = 0.0f;
+    if (wc.lane < n) {
+        const DView* vw = prm.views + img;
+        unit = get_unit(prm, vw, coord);
+        F4 ray = sub4(ld4(vw->center), coord);
+        ray = div4(ray, norm4(ray));
+        const float d = dot4(ray, normal);
+        if (0.0f < d) unit /= d; else unit = (float)(INT_MAX / 2);
+    }
+    const float w0 = rlf(unit, 0);
+    float w = fminf(1.0f, w0 / unit);
+    if (wc.lane == 0) w = 1.0f;
+    return w;
+}
+
+// Optim::computeINCC, optim.cpp:630-706
+DEV float compute_incc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n, float weights, int robust) {
+    if (n < 2) return 2.0f;
+    const int ref = rli(img, 0);
+    F4 px, py;
+    get_paxes(prm, prm.views + ref, coord, normal, px, py);
+    const int sz = min(prm.tau, n);
+    wc.evals++;
+    const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < sz);
+    float a0, a1, a2, b0, b1, b2;
+    if (!tex_sample_norm(prm, wc, f, 0, ref, a0, a1, a2)) return 2.0f;
+    float score = 0.0f, total = 0.0f;
+    for (int i = 1; i < sz; ++i) {
+        if (!tex_sample_norm(prm, wc, f, i, rli(img, i), b0, b1, b2)) continue;
+        const float w = rlf(weights, i);
+        total += w;
+        const float incc = (float)(1.0 - (double)tex_dot(prm, a0, a1, a2, b0, b1, b2));
+        score += (robust ? robustincc(incc) : incc) * w;
+    }
+    if (total == 0.0f) return 2.0f;
+    return score / total;
+}
+// PatchManager::computeNcc, patch_manager.cpp:401-404
+DEV float compute_ncc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n) {
+    const float w = compute_weights(prm, wc, coord, normal, img, n);
+    return 1.0f - unrobustincc(compute_incc(prm, wc, coord, normal, img, n, w, 1));
+}
+
+// Optim::setINCCs (vector), optim.cpp:708-746: returns the view-lane INCC array (reference vs every view)
+DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n, int robust) {
+    const int ref = rli(img, 0);
+    F4 px, py;
+    get_paxes(prm, prm.views + ref, coord, normal, px, py);
+    wc.evals++;
+    const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < n);
+    float a0, a1, a2, b0, b1, b2;
+    if (!tex_sample_norm(prm, wc, f, 0, ref, a0, a1, a2)) return 2.0f;
+    float incc = 2.0f;
+    if (wc.lane == 0) incc = 0.0f;
+    for (int i = 1; i < n; ++i) {
+        if (!tex_sample_norm(prm, wc, f, i, rli(img, i), b0, b1, b2)) continue;
+        const float d = 1.0f - tex_dot(prm, a0, a1, a2, b0, b1, b2);
+        const float val = robust ? robustincc(d) : d;
+        if (wc.lane == i) incc = val;
+    }
+    return incc;
+}
+
+// compaction of view-lane arrays through LDS scratch: keeps lanes with `keep`, order preserved
+DEV int compact1(int* scratch, const WaveCtx& wc, bool keep, int& a) {
+    const unsigned long long m = ballot(keep);
+    const int pos = __popcll(m & ((1ull << wc.lane) - 1ull));
+    __syncthreads();
+    if (keep) scratch[pos] = a;
+    __syncthreads();
+    a = scratch[wc.lane];
+    return __popcll(m);
+}
+
+// Optim::addImages, optim.cpp:165-205
+DEV void add_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c) {
+    const int ref = rli(c.img, 0);
+    bool visib = false;
+    for (int j = 0; j < c.nimg; ++j) visib |= (rli(c.img, j) == wc.lane);
+    bool q = false;
+    if (wc.lane < prm.nviews && wc.lane != ref && !visib) {
+        const DView* vw = prm.views + wc.lane;
+        const F3 ic = project(vw, c.coord, prm.level);
+        if (!(ic.x < 0.0f || vw->W[prm.level] - 1 <= ic.x || ic.y < 0.0f || vw->H[prm.level] - 1 <= ic.y)) {
+            F4 ray = sub4(ld4(vw->center), c.coord);
+            ray = div4(ray, norm4(ray));
+            q = prm.cosAngle0 <= dot4(ray, c.normal);
+        }
+    }
+    const unsigned long long m = ballot(q);
+    const int pos = c.nimg + __popcll(m & ((1ull << wc.lane) - 1ull));
+    __syncthreads();
+    if (wc.lane < c.nimg) scratch[wc.lane] = c.img;
+    if (q && pos < MVS_LISTCAP) scratch[pos] = wc.lane;
+    __syncthreads();
+    c.nimg = min(MVS_LISTCAP, c.nimg + (int)__popcll(m));
+    c.img = scratch[wc.lane];
+}
+
+// Optim::constraintImages, optim.cpp:207-219
+DEV void constraint_images(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c, float nccThreshold) {
+    const float inccs = set_inccs(prm, wc, c.coord, c.normal, c.img, c.nimg, 0);
+    const bool keep = wc.lane == 0 || (wc.lane < c.nimg && inccs < 1.0f - nccThreshold);
+    c.nimg = compact1(scratch, wc, keep, c.img);
+}
+
+// Optim::sortImages (isFixed = 1), optim.cpp:221-258
+DEV void sort_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c) {
+    F4 ray{0, 0, 0, 0};
+    float unit = 0.0f;
+    bool valid = false;
+    if (wc.lane < c.nimg) {  // computeUnits(patch, indexes, units, rays), optim.cpp:86-107
+        const DView* vw = prm.views + c.img;
+        ray = sub4(ld4(vw->center), c.coord);
+        ray = div4(ray, norm4(ray));
+        const float d = dot4(ray, c.normal);
+        valid = !(d <= 0.0f);
+        if (valid) unit = get_unit(prm, vw, c.coord) / d;
+    }
+    const unsigned long long vm = ballot(valid);
+    const int n0 = __popcll(vm);
+    if (n0 < 2) { c.nimg = 0; return; }
+    const int first = __ffsll((long long)vm) - 1;
+    if (wc.lane == first) unit = 0.0f;
+    unsigned long long active = vm;
+    int out = 0, k = 0;
+    const float thr = prm.sortThreshold;
+    while (active) {
+        const bool act = (active >> wc.lane) & 1ull;
+        const float m = wave_min(act ? unit : __int_as_float(0x7f800000));
+        const unsigned long long eq = ballot(act && unit == m);
+        const int sel = eq ? __ffsll((long long)eq) - 1 : __ffsll((long long)active) - 1;  // NaN guard: first remaining
+        const int vsel = rli(c.img, sel);
+        if (wc.lane == k) out = vsel;
+        const F4 rsel{rlf(ray.x, sel), rlf(ray.y, sel), rlf(ray.z, sel), rlf(ray.w, sel)};
+        active &= ~(1ull << sel);
+        if (act && wc.lane != sel) {
+            const float ftmp = fminf(thr, fmaxf(thr / 2.0f, 1.0f - dot4(rsel, ray)));
+            unit = unit * thr / ftmp;
+        }
+        ++k;
+    }
+    (void)scratch;
+    c.img = out;
+    c.nimg = k;
+}
+
+// PatchManager::setScales, patch_manager.cpp:378-399
+DEV void set_scales(const DParams& prm, const WaveCtx& wc, Cand& c) {
+    const int ref = rli(c.img, 0);
+    const DView* rv = prm.views + ref;
+    const float unit = get_unit(prm, rv, c.coord);
+    const float unit2 = 2.0f * unit;
+    F4 ray = sub4(c.coord, ld4(rv->center));
+    ray = div4(ray, norm4(ray));
+    const int num = min(prm.tau, c.nimg);
+    float dn = 0.0f;
+    if (wc.lane >= 1 && wc.lane < num) {
+        const DView* vw = prm.views + c.img;
+        dn = norm3(sub3(project(vw, c.coord, prm.level), project(vw, sub4(c.coord, mul4(ray, unit2)), prm.level)));
+    }
+    float ds = c.dscale;
+    for (int i = 1; i < num; ++i) ds += rlf(dn, i);
+    ds /= (float)(num - 1);
+    ds = unit2 / ds;
+    c.dscale = ds;
+    c.ascale = pm_atanf(ds / (unit * (float)prm.wsize / 2.0f));
+}
+
+// PhotoSet::checkAngles, photoSet.cpp:77-103 (window test on cosines)
+DEV int check_angles(const DParams& prm, const WaveCtx& wc, const Cand& c) {
+    F4 ray{0, 0, 0, 0};
+    if (wc.lane < c.nimg) {
+        ray = sub4(ld4((prm.views + c.img)->center), c.coord);
+        ray = div4(ray, norm4(ray));
+    }
+    int count = 0;
+    for (int j = 1; j < c.nimg; ++j) {
+        const F4 rj{rlf(ray.x, j), rlf(ray.y, j), rlf(ray.z, j), rlf(ray.w, j)};
+        const float d = fmaxf(-1.0f, fminf(1.0f, dot4(ray, rj)));
+        count += __popcll(ballot(wc.lane < j && d < prm.cosMinAngle && prm.cosMaxAngle < d));
+    }
+    return count < 1 ? -1 : 0;
+}
+
+// Optim::preProcess, optim.cpp:137-163
+DEV int pre_process(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c) {
+    add_images(prm, wc, scratch, c);
+    constraint_images(prm, wc, scratch, c, prm.nccThresholdBefore);
+    sort_images(prm, wc, scratch, c);
+    if (c.nimg > 0) set_scales(prm, wc, c);
+    if (c.nimg < prm.minImageNum) return -1;
+    if (check_angles(prm, wc, c) == -1) { c.nimg = 0; return -1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------ refinement
+struct RefineCtx {
+    F4 center, ray;
+    float dscale, ascale;
+    int ref;
+};
+// Optim::encode, optim.cpp:549-580
+DEV void encode(const DParams& prm, const RefineCtx& rc, F4 coord, F4 normal, float* x) {
+    x[0] = dot4(sub4(coord, rc.center), rc.ray) / rc.dscale;
+    const DView* vw = prm.views + rc.ref;
+    const F3 n3{normal.x, normal.y, normal.z};
+    const float fx = dot3(ld3(vw->xaxis), n3), fy = dot3(ld3(vw->yaxis), n3), fz = dot3(ld3(vw->zaxis), n3);
+    const float a2 = pm_asinf(fmaxf(-1.0f, fminf(1.0f, fy)));
+    const float cosb = pm_cosf(a2);
+    float a1;
+    if (cosb == 0.0f) a1 = 0.0f;
+    else {
+        const float sina = fx / cosb, cosa = -fz / cosb;
+        a1 = pm_acosf(fmaxf(-1.0f, fminf(1.0f, cosa)));
+        if (sina < 0.0f) a1 = -a1;
+    }
+    x[1] = a1 / rc.ascale;
+    x[2] = a2 / rc.ascale;
+}
+// Optim::decode, optim.cpp:582-599
+DEV void decode(const DParams& prm, const RefineCtx& rc, const float* x, F4& coord, F4& normal) {
+    const float t = rc.dscale * x[0];
+    coord = {fma_(t, rc.ray.x, rc.center.x), fma_(t, rc.ray.y, rc.center.y), fma_(t, rc.ray.z, rc.center.z), fma_(t, rc.ray.w, rc.center.w)};
+    const float angle1 = x[1] * rc.ascale, angle2 = x[2] * rc.ascale;
+    const float s1 = pm_sinf(angle1), c1 = pm_cosf(angle1), s2 = pm_sinf(angle2), c2 = pm_cosf(angle2);
+    const float fx = s1 * c2, fy = s2, fz = -c1 * c2;
+    const DView* vw = prm.views + rc.ref;
+    normal = {fma_(vw->zaxis[0], fz, fma_(vw->yaxis[0], fy, vw->xaxis[0] * fx)),
+              fma_(vw->zaxis[1], fz, fma_(vw->yaxis[1], fy, vw->xaxis[1] * fx)),
+              fma_(vw->zaxis[2], fz, fma_(vw->yaxis[2], fy, vw->xaxis[2] * fx)), 0.0f};
+}
+// Optim::cost_func, optim.cpp:401-468
+DEV double cost_func(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int img, int n, const float* x) {
+    F4 coord, normal, px, py;
+    decode(prm, rc, x, coord, normal);
+    get_paxes(prm, prm.views + rc.ref, coord, normal, px, py);
+    const int sz = min(prm.tau, n);
+    const int minimum = min(prm.minImageNum, sz);
+    wc.evals++;
+    const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < sz);
+    float a0, a1, a2, b0, b1, b2;
+    if (!tex_sample_norm(prm, wc, f, 0, rc.ref, a0, a1, a2)) return 2.0;
+    double ans = 0.0;
+    int denom = 0;
+    for (int i = 1; i < sz; ++i) {
+        if (!tex_sample_norm(prm, wc, f, i, rli(img, i), b0, b1, b2)) continue;
+        ans += (double)robustincc((float)(1.0 - (double)tex_dot(prm, a0, a1, a2, b0, b1, b2)));
+        denom++;
+    }
+    if (denom < minimum - 1) return 2.0;
+    return ans / (double)denom;
+}
+// Optim::refinePatch, optim.cpp:480-547, BOBYQA replaced by the halving random search
+DEV void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+    RefineCtx rc;
+    rc.center = c.coord;
+    rc.ref = rli(c.img, 0);
+    rc.ray = sub4(c.coord, ld4((prm.views + rc.ref)->center));
+    rc.ray = div4(rc.ray, norm4(rc.ray));
+    rc.dscale = c.dscale;
+    rc.ascale = prm.ascaleConst;
+    const float w = compute_weights(prm, wc, c.coord, c.normal, c.img, c.nimg);
+    float x[3];
+    encode(prm, rc, c.coord, c.normal, x);
+    const float amin = -23.99999f, amax = 23.99999f;
+    x[1] = fmaxf(fminf(x[1], amax), amin);
+    x[2] = fmaxf(fminf(x[2], amax), amin);
+    double fbest = cost_func(prm, wc, rc, c.img, c.nimg, x);
+    float rd = prm.rd0, ra = prm.ra0;
+    for (int k = 0; k < prm.refine_steps; ++k) {
+        float bx0 = x[0], bx1 = x[1], bx2 = x[2];
+        double fstep = 0.0;
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t draw = 16u + (uint32_t)(k * 3 + j) * 3u;
+            const float u0 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 0);
+            const float u1 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 1);
+            const float u2 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 2);
+            float cx[3];
+            cx[0] = (j == 1) ? x[0] : fma_(u0, rd, x[0]);
+            cx[1] = (j == 0) ? x[1] : fmaxf(fminf(fma_(u1, ra, x[1]), amax), amin);
+            cx[2] = (j == 0) ? x[2] : fmaxf(fminf(fma_(u2, ra, x[2]), amax), amin);
+            const double fj = cost_func(prm, wc, rc, c.img, c.nimg, cx);
+            if (j == 0 || fj < fstep) { fstep = fj; bx0 = cx[0]; bx1 = cx[1]; bx2 = cx[2]; }
+        }
+        if (fstep < fbest) { fbest = fstep; x[0] = bx0; x[1] = bx1; x[2] = bx2; }
+        rd *= 0.5f; ra *= 0.5f;
+    }
+    decode(prm, rc, x, c.coord, c.normal);
+    c.normal.w = 0.0f;
+    c.ncc = 1.0f - unrobustincc(compute_incc(prm, wc, c.coord, c.normal, c.img, c.nimg, w, 1));
+}
+
+// ------------------------------------------------------------------ post-processing
+// Optim::filterImagesByAngle, optim.cpp:325-346
+DEV void filter_images_by_angle(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c) {
+    bool bad = false;
+    if (wc.lane < c.nimg) {
+        F4 ray = sub4(ld4((prm.views + c.img)->center), c.coord);
+        ray = div4(ray, norm4(ray));
+        bad = dot4(ray, c.normal) < prm.cosAngle1;
+    }
+    const unsigned long long bm = ballot(bad);
+    if (bm & 1ull) { c.nimg = 0; return; }
+    c.nimg = compact1(scratch, wc, wc.lane < c.nimg && !bad, c.img);
+}
+DEV void set_grids(const DParams& prm, const WaveCtx& wc, Cand& c) {
+    c.gx = 0; c.gy = 0;
+    if (wc.lane < c.nimg) cell_of(prm, prm.views + c.img, c.coord, c.gx, c.gy);
+}
+// Optim::setRefImage, optim.cpp:348-383 with Optim::setINCCs (matrix), optim.cpp:748-783.
+// texs: LDS [LISTCAP][3][tstride] normalised textures.
+DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride, Cand& c) {
+    if (c.nimg == 0) return;
+    const int n = c.nimg;
+    const int ref = rli(c.img, 0);
+    F4 px, py;
+    get_paxes(prm, prm.views + ref, c.coord, c.normal, px, py);
+    wc.evals++;
+    const Frame f = make_frame(prm, c.coord, px, py, c.normal, c.img, wc.lane < n);
+    unsigned okmask = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        float t0, t1, t2;
+        if (tex_sample_norm(prm, wc, f, i, rli(c.img, i), t0, t1, t2)) {
+            okmask |= 1u << i;
+            if (wc.sample_lane) {
+                texs[(i * 3 + 0) * tstride + wc.lane] = t0;
+                texs[(i * 3 + 1) * tstride + wc.lane] = t1;
+                texs[(i * 3 + 2) * tstride + wc.lane] = t2;
+            }
+        }
+    }
+    __syncthreads();
+    float acc = 0.0f;  // view lane i: sum_j inccs[i][j], j ascending
+    for (int a = 0; a < n; ++a) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        const bool oka = (okmask >> a) & 1u;
+        if (oka && wc.sample_lane) {
+            a0 = texs[(a * 3 + 0) * tstride + wc.lane]; a1 = texs[(a * 3 + 1) * tstride + wc.lane]; a2 = texs[(a * 3 + 2) * tstride + wc.lane];
+        }
+        for (int b = a + 1; b < n; ++b) {
+            float val = 2.0f;
+            if (oka && ((okmask >> b) & 1u)) {
+                float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+                if (wc.sample_lane) {
+                    b0 = texs[(b * 3 + 0) * tstride + wc.lane]; b1 = texs[(b * 3 + 1) * tstride + wc.lane]; b2 = texs[(b * 3 + 2) * tstride + wc.lane];
+                }
+                val = robustincc(1.0f - tex_dot(prm, a0, a1, a2, b0, b1, b2));
+            }
+            if (wc.lane == a || wc.lane == b) acc += val;
+        }
+    }
+    const float big = (float)(INT_MAX / 2);
+    const bool cand = wc.lane < n && acc < big;
+    const float m = wave_min(cand ? acc : __int_as_float(0x7f800000));
+    const unsigned long long eq = ballot(cand && acc == m);
+    if (!eq) return;
+    const int refindex = __ffsll((long long)eq) - 1;
+    const int vref = rli(c.img, refindex), v0 = rli(c.img, 0);
+    if (wc.lane == 0) c.img = vref;
+    else if (wc.lane == refindex) c.img = v0;
+}
+
+// PatchManager::isVisible, patch_manager.cpp:335-376 (per view lane)
+DEV int is_visible(const DParams& prm, const Cand& c, int image, int ix, int iy, float strict) {
+    const DView* vw = prm.views + image;
+    if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) return 0;
+    if (prm.depth == 0) return 1;
+    const unsigned long long dp = prm.dpgrid[vw->cell_base + iy * vw->gw + ix];
+    if (dp == ~0ull) return 1;
+    const DPatch* q = prm.pool + (uint32_t)(dp & 0xffffffffull);
+    const F4 qc = ld4(q->coord);
+    F4 ray = sub4(c.coord, ld4(vw->center));
+    ray = div4(ray, norm4(ray));
+    const float diff = dot4(ray, sub4(c.coord, qc));
+    const double factor = fmin(2.0, 2.0 + (double)dot4(ray, c.normal));
+    const float lhs = get_unit(prm, vw, c.coord) * (float)prm.csize * strict;
+    return (double)diff < (double)lhs * factor ? 1 : 0;
+}
+// PatchManager::setVImagesVGrids, patch_manager.cpp:267-301
+DEV void set_vimages_vgrids(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c) {
+    bool visib = false;
+    for (int j = 0; j < c.nimg; ++j) visib |= (rli(c.img, j) == wc.lane);
+    for (int j = 0; j < c.nvimg; ++j) visib |= (rli(c.vimg, j) == wc.lane);
+    bool q = false;
+    int ix = 0, iy = 0;
+    if (wc.lane < prm.nviews && !visib) {
+        cell_of(prm, prm.views + wc.lane, c.coord, ix, iy);
+        q = is_visible(prm, c, wc.lane, ix, iy, prm.neighborThreshold) != 0;
+    }
+    const unsigned long long m = ballot(q);
+    const int pos = c.nvimg + __popcll(m & ((1ull << wc.lane) - 1ull));
+    __syncthreads();
+    if (wc.lane < c.nvimg) { scratch[wc.lane] = c.vimg; scratch[64 + wc.lane] = c.vgx; scratch[128 + wc.lane] = c.vgy; }
+    if (q && pos < MVS_LISTCAP) { scratch[pos] = wc.lane; scratch[64 + pos] = ix; scratch[128 + pos] = iy; }
+    __syncthreads();
+    c.nvimg = min(MVS_LISTCAP, c.nvimg + (int)__popcll(m));
+    c.vimg = scratch[wc.lane]; c.vgx = scratch[64 + wc.lane]; c.vgy = scratch[128 + wc.lane];
+}
+// PhotoSet::getMask(coord, level), photoSet.cpp:223-233
+DEV int get_mask_all(const DParams& prm, const WaveCtx& wc, const Cand& c) {
+    bool zero = false;
+    if (wc.lane < prm.nviews) {
+        const DView* vw = prm.views + wc.lane;
+        if (vw->mask) {
+            const F3 ic = project(vw, c.coord, prm.level);
+            const int ix = (int)floorf(ic.x + 0.5f), iy = (int)floorf(ic.y + 0.5f);
+            if (!(ix < 0 || vw->W[prm.level] <= ix || iy < 0 || vw->H[prm.level] <= iy))
+                zero = vw->mask[(size_t)iy * vw->W[prm.level] + ix] == 0;
+        }
+    }
+    return ballot(zero) ? 0 : -1;
+}
+DEV float score2(const Cand& c, float thr) { return fmaxf(0.0f, c.ncc - thr) * (float)c.nimg; }
+
+// Optim::postProcess, optim.cpp:260-298 (Optim::check is applied by the caller, which owns the cell lists)
+DEV int post_process(const DParams& prm, WaveCtx& wc, int* scratch, float* texs, int tstride, Cand& c) {
+    if (c.nimg < prm.minImageNum) return -1;
+    if (get_mask_all(prm, wc, c) == 0) return -1;
+    add_images(prm, wc, scratch, c);
+    constraint_images(prm, wc, scratch, c, prm.nccThreshold);
+    filter_images_by_angle(prm, wc, scratch, c);
+    if (c.nimg < prm.minImageNum) return -1;
+    set_grids(prm, wc, c);
+    set_ref_image(prm, wc, texs, tstride, c);
+    constraint_images(prm, wc, scratch, c, prm.nccThreshold);
+    if (c.nimg < prm.minImageNum) return -1;
+    set_grids(prm, wc, c);
+    c.tmp = score2(c, prm.nccThreshold);
+    if (prm.depth) set_vimages_vgrids(prm, wc, scratch, c);
+    return 0;
+}
+
+// ------------------------------------------------------------------ record <-> registers
+DEV void load_cand(const DPatch* p, const WaveCtx& wc, Cand& c) {
+    c.coord = ld4(p->coord);
+    c.normal = ld4(p->normal);
+    c.ncc = p->ncc; c.dscale = p->dscale; c.ascale = p->ascale; c.tmp = p->tmp;
+    c.nimg = min(p->nimages, MVS_LISTCAP);
+    c.nvimg = min(p->nvimages, MVS_LISTCAP);
+    c.img = (wc.lane < MVS_MAXI) ? (int)p->images[wc.lane] : 0;
+    c.vimg = (wc.lane < MVS_MAXI) ? (int)p->vimages[wc.lane] : 0;
+    c.gx = c.gy = c.vgx = c.vgy = 0;
+}
+DEV void store_cand(DPatch* p, const WaveCtx& wc, const Cand& c, int flags, int id) {
+    if (wc.lane == 0) {
+        p->coord[0] = c.coord.x; p->coord[1] = c.coord.y; p->coord[2] = c.coord.z; p->coord[3] = c.coord.w;
+        p->normal[0] = c.normal.x; p->normal[1] = c.normal.y; p->normal[2] = c.normal.z; p->normal[3] = c.normal.w;
+        p->ncc = c.ncc; p->dscale = c.dscale; p->ascale = c.ascale; p->tmp = c.tmp;
+        p->nimages = c.nimg; p->nvimages = c.nvimg; p->flags = flags; p->id = id;
+    }
+    if (wc.lane < MVS_MAXI) {
+        p->images[wc.lane] = (uint8_t)(wc.lane < c.nimg ? c.img : 0);
+        p->vimages[wc.lane] = (uint8_t)(wc.lane < c.nvimg ? c.vimg : 0);
+    }
+}
+DEV WaveCtx make_wave_ctx(const DParams& prm) {
+    WaveCtx wc;
+    wc.lane = lane_id();
+    wc.sample_lane = wc.lane < prm.wsz;
+    wc.fx = (float)(wc.lane % prm.wsize);
+    wc.fy = (float)(wc.lane / prm.wsize);
+    wc.evals = 0; wc.view_evals = 0;
+    return wc;
+}
+
+// Propagate::generatePatch, propagate.cpp:220-237.  `src` is in registers (view lanes hold m_images).
+DEV bool generate_patch(const DParams& prm, WaveCtx& wc, int* scratch, const Cand& src, F3 icoord, Cand& out) {
+    const int image = rli(src.img, 0);
+    const DView* vw = prm.views + image;
+    const float depth = dot4(ld4(vw->oaxis), src.coord);
+    const F3 nic{depth * icoord.x, depth * icoord.y, depth * icoord.z};
+    out.coord = unproject(vw, nic, prm.level);
+    out.normal = src.normal;
+    out.ncc = -1.0f; out.dscale = 0.0f; out.ascale = 0.0f; out.tmp = 0.0f;
+    out.nvimg = 0; out.vimg = 0; out.vgx = 0; out.vgy = 0;
+    // PatchManager::setGridsImages, patch_manager.cpp:223-239
+    int ix = 0, iy = 0;
+    bool keep = false;
+    if (wc.lane < src.nimg) {
+        const DView* v2 = prm.views + src.img;
+        cell_of(prm, v2, out.coord, ix, iy);
+        keep = 0 <= ix && ix < v2->gw && 0 <= iy && iy < v2->gh;
+    }
+    out.img = src.img; out.gx = ix; out.gy = iy;
+    const unsigned long long m = ballot(keep);
+    const int pos = __popcll(m & ((1ull << wc.lane) - 1ull));
+    __syncthreads();
+    if (keep) { scratch[pos] = out.img; scratch[64 + pos] = ix; scratch[128 + pos] = iy; }
+    __syncthreads();
+    out.nimg = __popcll(m);
+    out.img = scratch[wc.lane]; out.gx = scratch[64 + wc.lane]; out.gy = scratch[128 + wc.lane];
+    if (out.nimg == 0) return false;
+    out.ncc = compute_ncc(prm, wc, out.coord, out.normal, out.img, out.nimg);
+    return true;
+}
+
+}  // namespace mvsdev

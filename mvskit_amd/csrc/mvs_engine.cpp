@@ -1,0 +1,699 @@
+// mvs_engine.cpp -- host side of the C ABI in include/mvskit_engine.h: device memory, camera set-up,
+// the per-pass schedule (index build -> sweep -> commit) on one HIP stream, HIP-event timing.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mvskit_engine.h"
+#include "mvs_kernels.h"
+#include "mvs_types.h"
+
+static_assert(sizeof(mvs_patch) == sizeof(DPatch), "mvs_patch and DPatch must be the same bytes");
+static_assert(MVS_LIST_CAP == MVS_LISTCAP && MVS_MAX_IMAGES == MVS_MAXI, "limits out of sync");
+
+namespace {
+thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) {                                                                            \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(_e);                                     \
+            return MVS_ERR_HIP;                                                                            \
+        }                                                                                                  \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    int64_t cap = 0;
+    int ensure(int64_t n) {
+        if (n <= cap) return MVS_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const int64_t want = std::max<int64_t>(n, 16);
+        hipError_t e = hipMalloc((void**)&p, (size_t)want * sizeof(T));
+        if (e != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return MVS_ERR_HIP; }
+        cap = want;
+        return MVS_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+}  // namespace
+
+struct mvs_engine {
+    mvs_config cfg{};
+    DParams prm{};
+    hipStream_t stream = nullptr;
+    bool have_views = false;
+    std::vector<DView> hviews;
+    DevBuf<DView> dviews;
+    std::vector<uint32_t*> img_bufs;
+    std::vector<uint8_t*> mask_bufs;
+    int total_cells = 0;
+    // pool
+    DevBuf<DPatch> pool;
+    DevBuf<uint8_t> kill;
+    int64_t pool_n = 0;
+    bool ncc_dirty = false;
+    // index
+    DevBuf<int32_t> cnt, start, cursor, ids, vcnt, vstart, vcursor, vids, scan_tmp;
+    DevBuf<unsigned long long> dpgrid, best;
+    bool index_valid = false;
+    // sweep / staging
+    DevBuf<DPatch> staging;
+    DevBuf<int32_t> job_stage, job_nstage, job_cnt, job_base_scan, kill_cnt, kill_base, per_view;
+    DevBuf<unsigned long long> misc;  // [0] stage_counter, [1..2] fill_ncc evals, [3] trimmed
+    DevBuf<DCounters> counters;
+    DevBuf<int32_t> error_flag;
+    SweepArgs sa{};
+    bool staged = false;      // a pass has run and was not committed yet
+    bool counted = false;     // commit_count + scans done for the staged pass
+    int64_t n_new = 0, n_kill = 0;
+    std::vector<int32_t> h_per_view;
+    // probes / downloads
+    DevBuf<DPatch> tmp_rec_in, tmp_rec_out;
+    DevBuf<float> tmp_f_in, tmp_f_out;
+    DevBuf<int32_t> tmp_i;
+    DevBuf<uint8_t> tmp_bytes;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    mvs_timing timing{};
+};
+
+namespace {
+
+int64_t total_cells_of(const mvs_engine* e) { return e->total_cells; }
+
+void derive_params(mvs_engine* e) {  // PmMvps::init, pmmvps.cpp:32-36,54-67
+    const mvs_config& c = e->cfg;
+    DParams& p = e->prm;
+    p.nviews = c.nviews; p.level = c.level; p.csize = c.csize; p.wsize = c.wsize; p.wsz = c.wsize * c.wsize;
+    p.minImageNum = c.minImageNum;
+    p.tau = std::min(c.minImageNum * 2, c.nviews);
+    p.max_propag = c.max_propag;
+    p.cap = c.max_propag * c.csize * c.csize;
+    p.depth = c.depth; p.enable_check = c.enable_check;
+    p.seed = c.seed; p.refine_steps = c.refine_steps; p.rd0 = c.refine_rd0; p.ra0 = c.refine_ra0;
+    p.nccThreshold = c.nccThreshold;
+    p.nccThresholdBefore = c.nccThreshold - 0.3f;
+    // volatile: the libm calls below run at run time (the same glibc the oracle calls), not folded by the compiler
+    volatile float a0 = (float)(60.0f * M_PI / 180.0f), a1 = (float)(60.0f * M_PI / 180.0f);
+    volatile double amin = (double)c.maxAngleThreshold, amax = (double)a1;
+    volatile float typo = (float)(120.0f / M_PI * 180.0f);
+    volatile double d120 = 120.0f * M_PI / 180.0f, d10 = 10.0f * M_PI / 180.0f;
+    p.cosAngle0 = cosf(a0);
+    p.cosAngle1 = cosf(a1);
+    p.cosMinAngle = (float)cos(amin);
+    p.cosMaxAngle = (float)cos(amax);
+    p.cosNeighborTypo = cosf(typo);  // pmmvps.cpp:124 (deg/rad typo kept)
+    p.cosNeighbor120 = (float)cos(d120);
+    p.sortThreshold = (float)(1.0f - cos(d10));
+    p.ascaleConst = (float)(M_PI / 48.0f);
+    p.neighborThreshold = 0.5f; p.neighborThreshold1 = 1.0f;
+    p.quadThreshold = c.quadThreshold;
+}
+
+void invert3(const float* P, float* Minv) {  // Matrix3f::inverse (camera.cpp:304,335), in double
+    double a = P[0], b = P[1], c = P[2], d = P[4], e = P[5], f = P[6], g = P[8], h = P[9], i = P[10];
+    double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    double det = a * A + b * B + c * C;
+    double inv[9] = {A, -(b * i - c * h), b * f - c * e, B, a * i - c * g, -(a * f - c * d), C, -(a * h - b * g), a * e - b * d};
+    for (int k = 0; k < 9; ++k) Minv[k] = (float)(inv[k] / det);
+}
+inline float hfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+inline float hdot3(const float* a, const float* b) { return hfma(a[2], b[2], hfma(a[1], b[1], a[0] * b[0])); }
+inline float hdot4(const float* a, const float* b) { return hfma(a[3], b[3], hfma(a[2], b[2], hfma(a[1], b[1], a[0] * b[0]))); }
+inline void hcross(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// Camera::updateCamera (camera.cpp:65-100) + Optim::setAxesScales (optim.cpp:43-65)
+void setup_camera(const mvs_engine* e, DView& vw, const float* P0) {
+    const int maxLevel = e->cfg.level + 3;
+    for (int k = 0; k < 12; ++k) vw.P[0][k] = P0[k];
+    for (int l = 1; l < maxLevel; ++l) {
+        for (int k = 0; k < 12; ++k) vw.P[l][k] = vw.P[l - 1][k];
+        for (int k = 0; k < 8; ++k) vw.P[l][k] /= 2.0f;
+    }
+    invert3(vw.P[e->cfg.level], vw.Minv);
+    const float* r2 = &vw.P[0][8];
+    const float n = sqrtf(hdot3(r2, r2));
+    for (int k = 0; k < 4; ++k) vw.oaxis[k] = r2[k] / n;
+    {
+        const float* P = vw.P[0];
+        double a = P[0], b = P[1], c = P[2], d = P[4], ee = P[5], f = P[6], g = P[8], h = P[9], i = P[10];
+        double A = ee * i - f * h, B = -(d * i - f * g), C = d * h - ee * g;
+        double det = a * A + b * B + c * C;
+        double inv[9] = {A, -(b * i - c * h), b * f - c * ee, B, a * i - c * g, -(a * f - c * d), C, -(a * h - b * g), a * ee - b * d};
+        double q[3] = {P[3], P[7], P[11]};
+        vw.center[0] = (float)(-(inv[0] * q[0] + inv[1] * q[1] + inv[2] * q[2]) / det);
+        vw.center[1] = (float)(-(inv[3] * q[0] + inv[4] * q[1] + inv[5] * q[2]) / det);
+        vw.center[2] = (float)(-(inv[6] * q[0] + inv[7] * q[1] + inv[8] * q[2]) / det);
+        vw.center[3] = 1.0f;
+    }
+    for (int k = 0; k < 3; ++k) vw.zaxis[k] = vw.oaxis[k];
+    float xa[3] = {vw.P[0][0], vw.P[0][1], vw.P[0][2]};
+    hcross(vw.zaxis, xa, vw.yaxis);
+    const float yn = sqrtf(hdot3(vw.yaxis, vw.yaxis));
+    for (int k = 0; k < 3; ++k) vw.yaxis[k] /= yn;
+    hcross(vw.yaxis, vw.zaxis, vw.xaxis);
+    const float x4[4] = {vw.xaxis[0], vw.xaxis[1], vw.xaxis[2], 0.0f}, y4[4] = {vw.yaxis[0], vw.yaxis[1], vw.yaxis[2], 0.0f};
+    vw.ipscale = hdot4(&vw.P[0][0], x4) + hdot4(&vw.P[0][4], y4);
+}
+
+void free_views(mvs_engine* e) {
+    for (uint32_t* p : e->img_bufs) if (p) (void)hipFree(p);
+    for (uint8_t* p : e->mask_bufs) if (p) (void)hipFree(p);
+    e->img_bufs.clear(); e->mask_bufs.clear();
+    e->have_views = false;
+}
+
+DParams current_params(mvs_engine* e) {
+    DParams p = e->prm;
+    p.views = e->dviews.p;
+    p.pool = e->pool.p;
+    p.pool_n = e->pool_n;
+    p.total_cells = e->total_cells;
+    p.csr_start = e->start.p; p.csr_ids = e->ids.p;
+    p.vcsr_start = e->vstart.p; p.vcsr_ids = e->vids.p;
+    p.dpgrid = e->dpgrid.p;
+    return p;
+}
+
+bool want_vgrid(const mvs_engine* e) { return e->prm.depth >= 2 && e->prm.enable_check; }
+
+// Index build: CSR of every (view, cell) list sorted by (ncc desc, id asc), trim to MAX_NUM_OF_PATCHES, depth maps.
+int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
+    hipStream_t st = e->stream;
+    const int64_t nc = e->total_cells;
+    DParams p = current_params(e);
+    if (e->ncc_dirty) {
+        HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
+        mvsk_fill_ncc(p, e->misc.p + 1, st);
+        e->ncc_dirty = false;
+    }
+    const bool vg = want_vgrid(e);
+    HIPCHK(hipMemsetAsync(e->cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
+    if (vg) HIPCHK(hipMemsetAsync(e->vcnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
+    mvsk_index_count(p, e->cnt.p, vg ? e->vcnt.p : nullptr, st);
+    mvsk_exclusive_scan(e->cnt.p, e->start.p, nc, e->scan_tmp.p, st);
+    if (vg) mvsk_exclusive_scan(e->vcnt.p, e->vstart.p, nc, e->scan_tmp.p, st);
+    int32_t tot = 0, vtot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, e->start.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (vg) HIPCHK(hipMemcpyAsync(&vtot, e->vstart.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (int r = e->ids.ensure(tot + 16)) return r;
+    if (vg) if (int r = e->vids.ensure(vtot + 16)) return r;
+    p = current_params(e);
+    HIPCHK(hipMemsetAsync(e->cursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
+    if (vg) HIPCHK(hipMemsetAsync(e->vcursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
+    mvsk_index_fill(p, e->start.p, e->cursor.p, e->ids.p, vg ? e->vstart.p : nullptr, vg ? e->vcursor.p : nullptr, vg ? e->vids.p : nullptr, st);
+    HIPCHK(hipMemsetAsync(e->misc.p + 3, 0, sizeof(unsigned long long), st));
+    mvsk_index_sort_trim(p, e->start.p, e->ids.p, 1, e->misc.p + 3, st);
+    if (vg) mvsk_index_sort_trim(p, e->vstart.p, e->vids.p, 0, e->misc.p + 3, st);
+    HIPCHK(hipMemsetAsync(e->dpgrid.p, 0xff, (size_t)nc * sizeof(unsigned long long), st));
+    mvsk_depth_maps(p, e->dpgrid.p, st);
+    if (trimmed_out) {
+        HIPCHK(hipMemcpyAsync(trimmed_out, e->misc.p + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    HIPCHK(hipGetLastError());
+    e->index_valid = true;
+    return MVS_OK;
+}
+
+int ensure_counts(mvs_engine* e) {  // commit_count + scans for the staged pass
+    if (e->counted) return MVS_OK;
+    hipStream_t st = e->stream;
+    const int64_t nj = e->sa.njobs;
+    e->n_new = 0; e->n_kill = 0;
+    e->h_per_view.assign(e->cfg.nviews, 0);
+    if (nj > 0) {
+        mvsk_commit_count(e->sa, e->job_cnt.p, st);
+        mvsk_exclusive_scan(e->job_cnt.p, e->job_base_scan.p, nj, e->scan_tmp.p, st);
+        std::vector<int32_t> bounds(e->sa.nsweep_views + 1);
+        for (int s = 0; s < e->sa.nsweep_views; ++s)
+            HIPCHK(hipMemcpyAsync(&bounds[s], e->job_base_scan.p + e->sa.job_base[s], sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&bounds[e->sa.nsweep_views], e->job_base_scan.p + nj, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        e->n_new = bounds[e->sa.nsweep_views];
+        for (int s = 0; s < e->sa.nsweep_views; ++s) e->h_per_view[e->sa.sweep_views[s]] = bounds[s + 1] - bounds[s];
+    }
+    if (e->pool_n > 0) {
+        mvsk_kill_count(e->kill.p, e->pool_n, e->kill_cnt.p, st);
+        mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, e->scan_tmp.p, st);
+        int32_t nk = 0;
+        HIPCHK(hipMemcpyAsync(&nk, e->kill_base.p + e->pool_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        e->n_kill = nk;
+    }
+    e->counted = true;
+    return MVS_OK;
+}
+
+void add_counters(mvs_counters& a, const mvs_counters& b) {
+    a.candidates += b.candidates; a.prefiltered += b.prefiltered; a.patches += b.patches; a.fail0 += b.fail0; a.fail1 += b.fail1;
+    a.inserted += b.inserted; a.replaced += b.replaced; a.evals += b.evals; a.view_evals += b.view_evals; a.trimmed += b.trimmed;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mvs_last_error(void) { return g_err.c_str(); }
+
+int mvs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mvs_default_config(mvs_config* c) {  // Option::Option, option.cpp:19-33
+    memset(c, 0, sizeof *c);
+    c->level = 1; c->csize = 2; c->wsize = 7; c->minImageNum = 3; c->max_propag = 2;
+    c->nccThreshold = 0.7f; c->maxAngleThreshold = (float)(10.0f * M_PI / 180.0f); c->quadThreshold = 2.5f;
+    c->depth = 1; c->seed = 1; c->refine_steps = 8; c->refine_rd0 = 4.0f; c->refine_ra0 = 4.0f; c->enable_check = 1;
+    c->view_begin = 0; c->view_stride = 1; c->device = 0; c->max_patches = 0;
+}
+
+int mvs_engine_create(const mvs_config* cfg, mvs_engine** out) {
+    if (!cfg || !out) { g_err = "mvs_engine_create: null argument"; return MVS_ERR_ARG; }
+    if (cfg->nviews < 1 || cfg->nviews > MVS_MAXVIEWS || cfg->wsize < 1 || cfg->wsize > 8 || cfg->csize < 1 || cfg->level < 0 ||
+        cfg->level > 4 || cfg->max_propag < 1 || cfg->max_propag > 16 || cfg->max_propag * cfg->csize * cfg->csize > MVS_CAPMAX ||
+        cfg->view_stride < 1 || cfg->view_begin < 0 || cfg->minImageNum < 1) {
+        g_err = "mvs_engine_create: configuration out of range (nviews <= 64, wsize <= 8, max_propag*csize^2 <= 32)";
+        return MVS_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_err = "mvs_engine_create: no HIP device (the engine has no CPU path)"; return MVS_ERR_NO_DEVICE; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_err = "mvs_engine_create: bad device ordinal"; return MVS_ERR_ARG; }
+    HIPCHK(hipSetDevice(cfg->device));
+    mvs_engine* e = new mvs_engine();
+    e->cfg = *cfg;
+    derive_params(e);
+    hipError_t he = hipStreamCreate(&e->stream);
+    if (he != hipSuccess) { g_err = std::string("hipStreamCreate: ") + hipGetErrorString(he); delete e; return MVS_ERR_HIP; }
+    for (auto& ev : e->ev) (void)hipEventCreate(&ev);
+    if (e->misc.ensure(8) || e->counters.ensure(1) || e->error_flag.ensure(1)) { delete e; return MVS_ERR_HIP; }
+    (void)hipMemset(e->misc.p, 0, 8 * sizeof(unsigned long long));
+    (void)hipMemset(e->error_flag.p, 0, sizeof(int32_t));
+    *out = e;
+    return MVS_OK;
+}
+
+int mvs_engine_destroy(mvs_engine* e) {
+    if (!e) return MVS_OK;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipStreamSynchronize(e->stream);
+    free_views(e);
+    e->dviews.release(); e->pool.release(); e->kill.release();
+    e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
+    e->vcursor.release(); e->vids.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
+    e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
+    e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
+    e->tmp_rec_in.release(); e->tmp_rec_out.release(); e->tmp_f_in.release(); e->tmp_f_out.release(); e->tmp_i.release(); e->tmp_bytes.release();
+    for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+    return MVS_OK;
+}
+
+int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) {
+    if (!e || !views || nviews != e->cfg.nviews) { g_err = "mvs_engine_set_views: nviews must equal the configured number of views"; return MVS_ERR_ARG; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->stream;
+    free_views(e);
+    const int maxLevel = e->cfg.level + 3;
+    e->hviews.assign(nviews, DView{});
+    int cell_base = 0;
+    size_t max_bytes = 0;
+    for (int v = 0; v < nviews; ++v) {
+        if (views[v].width < 8 || views[v].height < 8 || !views[v].rgb) { g_err = "mvs_engine_set_views: bad view"; return MVS_ERR_ARG; }
+        max_bytes = std::max(max_bytes, (size_t)views[v].width * views[v].height * 3);
+    }
+    if (int r = e->tmp_bytes.ensure((int64_t)max_bytes)) return r;
+    for (int v = 0; v < nviews; ++v) {
+        DView& vw = e->hviews[v];
+        vw.W[0] = views[v].width; vw.H[0] = views[v].height;
+        for (int l = 1; l < maxLevel; ++l) { vw.W[l] = vw.W[l - 1] / 2; vw.H[l] = vw.H[l - 1] / 2; }
+        setup_camera(e, vw, views[v].P);
+        const size_t n0 = (size_t)vw.W[0] * vw.H[0];
+        HIPCHK(hipMemcpyAsync(e->tmp_bytes.p, views[v].rgb, n0 * 3, hipMemcpyHostToDevice, st));
+        for (int l = 0; l < maxLevel; ++l) {
+            uint32_t* buf = nullptr;
+            HIPCHK(hipMalloc((void**)&buf, std::max<size_t>((size_t)vw.W[l] * vw.H[l], 1) * sizeof(uint32_t)));
+            e->img_bufs.push_back(buf);
+            vw.img[l] = buf;
+            if (l == 0) mvsk_rgb_to_rgba(e->tmp_bytes.p, buf, (int64_t)n0, st);
+            else mvsk_pyr_down(vw.img[l - 1], vw.W[l - 1], vw.H[l - 1], buf, vw.W[l], vw.H[l], st);
+        }
+        vw.mask = nullptr;
+        if (views[v].mask) {  // Image::alloc mask handling (image.cpp:166-183) + buildMaskPyramid (image.cpp:717-747)
+            HIPCHK(hipStreamSynchronize(st));
+            uint8_t* prev = nullptr;
+            for (int l = 0; l <= e->cfg.level; ++l) {
+                uint8_t* m = nullptr;
+                HIPCHK(hipMalloc((void**)&m, std::max<size_t>((size_t)vw.W[l] * vw.H[l], 1)));
+                e->mask_bufs.push_back(m);
+                if (l == 0) {
+                    HIPCHK(hipMemcpyAsync(m, views[v].mask, n0, hipMemcpyHostToDevice, st));
+                    mvsk_mask_binarise(m, (int64_t)n0, st);
+                } else mvsk_mask_down(prev, vw.W[l - 1], vw.H[l - 1], m, vw.W[l], vw.H[l], st);
+                prev = m;
+            }
+            vw.mask = prev;
+        }
+        HIPCHK(hipStreamSynchronize(st));  // tmp_bytes is reused by the next view
+        vw.gh = (vw.H[e->cfg.level] + e->cfg.csize - 1) / e->cfg.csize;  // patch_manager.cpp:36-37
+        vw.gw = (vw.W[e->cfg.level] + e->cfg.csize - 1) / e->cfg.csize;
+        vw.cell_base = cell_base;
+        cell_base += vw.gw * vw.gh;
+    }
+    e->total_cells = cell_base;
+    if (int r = e->dviews.ensure(nviews)) return r;
+    HIPCHK(hipMemcpyAsync(e->dviews.p, e->hviews.data(), sizeof(DView) * nviews, hipMemcpyHostToDevice, st));
+    const int64_t nc = e->total_cells;
+    if (e->cnt.ensure(nc + 2) || e->start.ensure(nc + 2) || e->cursor.ensure(nc + 2) || e->vcnt.ensure(nc + 2) || e->vstart.ensure(nc + 2) ||
+        e->vcursor.ensure(nc + 2) || e->dpgrid.ensure(nc + 2) || e->best.ensure(nc + 2))
+        return MVS_ERR_HIP;
+    const int64_t pool_cap = e->cfg.max_patches > 0 ? e->cfg.max_patches : 4 * nc;
+    if (e->pool.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;
+    HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)pool_cap, st));
+    // jobs of one colour pass over every view (upper bound, used to size the staging bookkeeping)
+    int64_t njobs_max = 0;
+    for (int v = 0; v < nviews; ++v) njobs_max += (int64_t)((e->hviews[v].gw + 1) / 2) * e->hviews[v].gh;
+    const int maxstage = 2 * e->prm.cap * e->prm.max_propag;
+    if (e->job_stage.ensure(njobs_max * maxstage) || e->job_nstage.ensure(njobs_max + 2) || e->job_cnt.ensure(njobs_max + 2) ||
+        e->job_base_scan.ensure(njobs_max + 2) || e->per_view.ensure(MVS_MAXVIEWS))
+        return MVS_ERR_HIP;
+    const int64_t scan_n = std::max<int64_t>(std::max<int64_t>(nc, pool_cap), njobs_max);
+    if (e->scan_tmp.ensure(scan_n / 256 + 4096)) return MVS_ERR_HIP;
+    if (e->staging.ensure(std::max<int64_t>(pool_cap / 2, 1024))) return MVS_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(st));
+    e->pool_n = 0;
+    e->have_views = true;
+    e->index_valid = false;
+    e->staged = false;
+    return MVS_OK;
+}
+
+int mvs_engine_grid_dims(mvs_engine* e, int view, int* gw, int* gh) {
+    if (!e || !e->have_views || view < 0 || view >= e->cfg.nviews) { g_err = "mvs_engine_grid_dims: bad view / views not set"; return MVS_ERR_STATE; }
+    if (gw) *gw = e->hviews[view].gw;
+    if (gh) *gh = e->hviews[view].gh;
+    return MVS_OK;
+}
+
+int mvs_engine_get_pyramid(mvs_engine* e, int view, int level, uint8_t* rgb_out, int* W, int* H) {
+    if (!e || !e->have_views || view < 0 || view >= e->cfg.nviews || level < 0 || level >= e->cfg.level + 3) { g_err = "mvs_engine_get_pyramid: bad argument"; return MVS_ERR_ARG; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const DView& vw = e->hviews[view];
+    if (W) *W = vw.W[level];
+    if (H) *H = vw.H[level];
+    if (!rgb_out) return MVS_OK;
+    const int64_t n = (int64_t)vw.W[level] * vw.H[level];
+    if (int r = e->tmp_bytes.ensure(n * 3)) return r;
+    mvsk_rgba_to_rgb(vw.img[level], e->tmp_bytes.p, n, e->stream);
+    HIPCHK(hipMemcpyAsync(rgb_out, e->tmp_bytes.p, (size_t)n * 3, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MVS_OK;
+}
+
+int mvs_engine_set_thresholds(mvs_engine* e, float ncc, float before, int depth) {
+    if (!e) return MVS_ERR_ARG;
+    e->prm.nccThreshold = ncc; e->prm.nccThresholdBefore = before; e->prm.depth = depth;
+    return MVS_OK;
+}
+int mvs_engine_get_thresholds(mvs_engine* e, float* ncc, float* before, int* depth) {
+    if (!e) return MVS_ERR_ARG;
+    if (ncc) *ncc = e->prm.nccThreshold;
+    if (before) *before = e->prm.nccThresholdBefore;
+    if (depth) *depth = e->prm.depth;
+    return MVS_OK;
+}
+int mvs_engine_update_threshold(mvs_engine* e) {  // pmmvps.cpp:70-74 and :105
+    if (!e) return MVS_ERR_ARG;
+    e->prm.nccThreshold -= 0.05f; e->prm.nccThresholdBefore -= 0.05f; ++e->prm.depth;
+    return MVS_OK;
+}
+
+int mvs_engine_upload_patches(mvs_engine* e, int64_t n, const mvs_patch* patches) {
+    if (!e || !e->have_views) { g_err = "mvs_engine_upload_patches: views not set"; return MVS_ERR_STATE; }
+    if (n < 0 || (n > 0 && !patches)) return MVS_ERR_ARG;
+    if (e->staged) { g_err = "mvs_engine_upload_patches: a pass is waiting for its commit"; return MVS_ERR_STATE; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    // readPatches (patch_manager.cpp:450-463): m_fix = 0, m_tmp = score2, m_vimages cleared, empty m_images dropped
+    std::vector<mvs_patch> recs;
+    recs.reserve((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        mvs_patch p = patches[i];
+        p.nimages = std::min(p.nimages, MVS_LIST_CAP);
+        if (p.nimages <= 0) continue;
+        p.nvimages = 0;
+        memset(p.vimages, 0, sizeof p.vimages);
+        p.tmp = std::max(0.0f, p.ncc - e->prm.nccThreshold) * p.nimages;
+        p.flags = 1;
+        p.id = 0;
+        recs.push_back(p);
+    }
+    if (e->pool_n + (int64_t)recs.size() > e->pool.cap) { g_err = "mvs_engine_upload_patches: patch pool capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
+    if (!recs.empty()) HIPCHK(hipMemcpyAsync(e->pool.p + e->pool_n, recs.data(), recs.size() * sizeof(mvs_patch), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->pool_n += (int64_t)recs.size();
+    e->ncc_dirty = true;
+    e->index_valid = false;
+    return MVS_OK;
+}
+
+int mvs_engine_clear_patches(mvs_engine* e) {
+    if (!e) return MVS_ERR_ARG;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    if (e->kill.p) HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)e->kill.cap, e->stream));
+    e->pool_n = 0; e->staged = false; e->counted = false; e->index_valid = false;
+    return MVS_OK;
+}
+
+int mvs_engine_num_patches(mvs_engine* e, int64_t* n_alive) {
+    if (!e || !n_alive) return MVS_ERR_ARG;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    *n_alive = 0;
+    if (e->pool_n == 0) return MVS_OK;
+    mvsk_alive_count(e->pool.p, e->pool_n, e->kill_cnt.p, e->stream);
+    mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, e->scan_tmp.p, e->stream);
+    int32_t tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, e->kill_base.p + e->pool_n, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *n_alive = tot;
+    return MVS_OK;
+}
+
+int mvs_engine_download_patches(mvs_engine* e, int64_t cap, mvs_patch* out, int64_t* n) {
+    if (!e || !n) return MVS_ERR_ARG;
+    int64_t alive = 0;
+    if (int r = mvs_engine_num_patches(e, &alive)) return r;  // leaves kill_base = exclusive scan of the alive flags
+    *n = alive;
+    if (!out || alive == 0) return MVS_OK;
+    const int64_t m = std::min(cap, alive);
+    if (int r = e->tmp_rec_out.ensure(alive)) return r;
+    mvsk_alive_gather(e->pool.p, e->pool_n, e->kill_base.p, e->tmp_rec_out.p, alive, e->stream);
+    HIPCHK(hipMemcpyAsync(out, e->tmp_rec_out.p, (size_t)m * sizeof(mvs_patch), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MVS_OK;
+}
+
+int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
+    if (!e || !e->have_views) { g_err = "mvs_engine_pass: views not set"; return MVS_ERR_STATE; }
+    if (e->staged) { g_err = "mvs_engine_pass: the previous pass was not committed"; return MVS_ERR_STATE; }
+    if (e->prm.depth >= 2 && e->prm.enable_check) { g_err = "mvs_engine_pass: Optim::check (depth >= 2) is not built into this engine yet; set enable_check = 0"; return MVS_ERR_ARG; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->stream;
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    unsigned long long trimmed = 0;
+    if (int r = build_index(e, &trimmed)) return r;
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    // jobs: one per (swept view, row, half column) of the pass colour
+    SweepArgs& a = e->sa;
+    memset(&a, 0, sizeof a);
+    a.iter = iter; a.inc = (iter % 2 == 0) ? 1 : -1; a.colour = pass & 1;
+    int64_t nj = 0;
+    for (int v = e->cfg.view_begin; v < e->cfg.nviews; v += e->cfg.view_stride) {
+        a.sweep_views[a.nsweep_views] = v;
+        a.job_base[a.nsweep_views] = (int32_t)nj;
+        ++a.nsweep_views;
+        nj += (int64_t)((e->hviews[v].gw + 1) / 2) * e->hviews[v].gh;
+    }
+    a.njobs = nj;
+    a.staging = e->staging.p; a.staging_cap = e->staging.cap;
+    a.stage_counter = e->misc.p;
+    a.job_stage = e->job_stage.p; a.job_nstage = e->job_nstage.p;
+    a.maxstage = 2 * e->prm.cap * e->prm.max_propag;
+    a.kill = e->kill.p;
+    a.counters = e->counters.p;
+    a.error_flag = e->error_flag.p;
+    HIPCHK(hipMemsetAsync(e->misc.p, 0, sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(e->counters.p, 0, sizeof(DCounters), st));
+    HIPCHK(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
+    const DParams p = current_params(e);
+    mvsk_sweep(p, a, st);
+    HIPCHK(hipEventRecord(e->ev[2], st));
+    DCounters hc;
+    int32_t herr = 0;
+    HIPCHK(hipMemcpyAsync(&hc, e->counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&herr, e->error_flag.p, sizeof herr, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->timing.index_ms = ms;
+    (void)hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->timing.sweep_ms = ms;
+    e->timing.commit_ms = 0.0f; e->timing.sweep_launches = 1;
+    e->staged = true; e->counted = false;
+    if (out) {
+        out->candidates = (int64_t)hc.candidates; out->prefiltered = (int64_t)hc.prefiltered; out->patches = (int64_t)hc.patches;
+        out->fail0 = (int64_t)hc.fail0; out->fail1 = (int64_t)hc.fail1; out->inserted = (int64_t)hc.inserted; out->replaced = (int64_t)hc.replaced;
+        out->evals = (int64_t)hc.evals; out->view_evals = (int64_t)hc.view_evals; out->trimmed = (int64_t)trimmed;
+    }
+    if (herr) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
+    return MVS_OK;
+}
+
+int mvs_engine_export_counts(mvs_engine* e, int64_t* n_new, int64_t* n_kill, int32_t* per_view_new) {
+    if (!e || !e->staged) { g_err = "mvs_engine_export_counts: no pass to export"; return MVS_ERR_STATE; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    if (int r = ensure_counts(e)) return r;
+    if (n_new) *n_new = e->n_new;
+    if (n_kill) *n_kill = e->n_kill;
+    if (per_view_new) for (int v = 0; v < e->cfg.nviews; ++v) per_view_new[v] = e->h_per_view[v];
+    return MVS_OK;
+}
+
+int mvs_engine_export_device(mvs_engine* e, void* d_new, int64_t cap_new, void* d_kill, int64_t cap_kill) {
+    if (!e || !e->staged) { g_err = "mvs_engine_export_device: no pass to export"; return MVS_ERR_STATE; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    if (int r = ensure_counts(e)) return r;
+    if (e->n_new > cap_new || e->n_kill > cap_kill) { g_err = "mvs_engine_export_device: buffers too small"; return MVS_ERR_CAPACITY; }
+    if (e->n_new > 0) mvsk_commit_copy(e->sa, e->job_base_scan.p, (DPatch*)d_new, cap_new, nullptr, 1, e->stream);
+    if (e->n_kill > 0) mvsk_kill_export(e->kill.p, e->pool_n, e->kill_base.p, (int32_t*)d_kill, cap_kill, e->stream);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MVS_OK;
+}
+
+int mvs_engine_commit_device(mvs_engine* e, const void* d_new, int64_t n_new, const void* d_kill, int64_t n_kill) {
+    if (!e || !e->have_views) return MVS_ERR_STATE;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->stream;
+    if (e->pool_n + n_new > e->pool.cap) { g_err = "mvs_engine_commit_device: patch pool capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
+    HIPCHK(hipEventRecord(e->ev[2], st));
+    mvsk_apply_kill_ids(e->pool.p, (const int32_t*)d_kill, n_kill, e->pool_n, st);
+    mvsk_append_records(e->pool.p, e->pool_n, (const DPatch*)d_new, n_new, st);
+    if (e->pool_n > 0) HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));
+    HIPCHK(hipEventRecord(e->ev[3], st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->timing.commit_ms = ms;
+    e->pool_n += n_new;
+    e->staged = false; e->counted = false; e->index_valid = false;
+    return MVS_OK;
+}
+
+int mvs_engine_commit_local(mvs_engine* e) {
+    if (!e || !e->staged) { g_err = "mvs_engine_commit_local: no pass to commit"; return MVS_ERR_STATE; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->stream;
+    HIPCHK(hipEventRecord(e->ev[2], st));
+    if (int r = ensure_counts(e)) return r;
+    if (e->pool_n + e->n_new > e->pool.cap) { g_err = "mvs_engine_commit_local: patch pool capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
+    if (e->n_new > 0) mvsk_commit_copy(e->sa, e->job_base_scan.p, e->pool.p + e->pool_n, e->pool.cap - e->pool_n, nullptr, 0, st);
+    mvsk_apply_kill_flags(e->pool.p, e->kill.p, e->pool_n, st);
+    HIPCHK(hipEventRecord(e->ev[3], st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->timing.commit_ms = ms;
+    e->pool_n += e->n_new;
+    e->staged = false; e->counted = false; e->index_valid = false;
+    return MVS_OK;
+}
+
+int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out) {  // Propagate::run, propagate.cpp:28-64
+    mvs_counters total;
+    memset(&total, 0, sizeof total);
+    mvs_timing tt{};
+    for (int pass = 0; pass < 2; ++pass) {
+        mvs_counters c;
+        memset(&c, 0, sizeof c);
+        if (int r = mvs_engine_pass(e, iter, pass, &c)) return r;
+        if (int r = mvs_engine_commit_local(e)) return r;
+        add_counters(total, c);
+        tt.index_ms += e->timing.index_ms; tt.sweep_ms += e->timing.sweep_ms; tt.commit_ms += e->timing.commit_ms; tt.sweep_launches += 1;
+    }
+    e->timing = tt;
+    if (out) *out = total;
+    return MVS_OK;
+}
+
+int mvs_engine_last_timing(mvs_engine* e, mvs_timing* t) {
+    if (!e || !t) return MVS_ERR_ARG;
+    *t = e->timing;
+    return MVS_OK;
+}
+
+int mvs_engine_depth_normal_map(mvs_engine* e, int view, int kind, float* depth, float* normal, int32_t* ids) {
+    if (!e || !e->have_views || view < 0 || view >= e->cfg.nviews || kind < 0 || kind > 1) { g_err = "mvs_engine_depth_normal_map: bad argument"; return MVS_ERR_ARG; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->stream;
+    const DView& vw = e->hviews[view];
+    const int ncells = vw.gw * vw.gh;
+    const DParams p = current_params(e);
+    const unsigned long long* sel = nullptr;
+    if (kind == 0) {
+        HIPCHK(hipMemsetAsync(e->dpgrid.p, 0xff, (size_t)e->total_cells * sizeof(unsigned long long), st));
+        mvsk_depth_maps(p, e->dpgrid.p, st);
+        sel = e->dpgrid.p + vw.cell_base;
+        e->index_valid = false;
+    } else {
+        HIPCHK(hipMemsetAsync(e->best.p, 0, (size_t)ncells * sizeof(unsigned long long), st));
+        mvsk_best_ncc_map(p, view, e->best.p, st);
+        sel = e->best.p;
+    }
+    if (e->tmp_f_out.ensure((int64_t)ncells * 4) || e->tmp_i.ensure(ncells)) return MVS_ERR_HIP;
+    mvsk_map_extract(p, view, kind, sel, e->tmp_f_out.p, e->tmp_f_out.p + ncells, e->tmp_i.p, ncells, st);
+    if (depth) HIPCHK(hipMemcpyAsync(depth, e->tmp_f_out.p, (size_t)ncells * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (normal) HIPCHK(hipMemcpyAsync(normal, e->tmp_f_out.p + ncells, (size_t)ncells * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (ids) HIPCHK(hipMemcpyAsync(ids, e->tmp_i.p, (size_t)ncells * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return MVS_OK;
+}
+
+int mvs_engine_probe(mvs_engine* e, int op, int64_t n, const mvs_patch* in_rec, const float* in_f, mvs_patch* out_rec, float* out_f, int32_t* out_i) {
+    if (!e || !e->have_views || n < 0 || op < 0 || op > 5) { g_err = "mvs_engine_probe: bad argument / views not set"; return MVS_ERR_ARG; }
+    if (n == 0) return MVS_OK;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->stream;
+    if (op == MVS_PROBE_POSTPROCESS && e->prm.depth > 0) if (int r = build_index(e, nullptr)) return r;  // setVImagesVGrids reads m_dpgrids
+    const int64_t nf_out = op == MVS_PROBE_MATH ? 5 * n : n;
+    if (e->tmp_rec_in.ensure(n) || e->tmp_rec_out.ensure(n) || e->tmp_f_in.ensure(n) || e->tmp_f_out.ensure(nf_out) || e->tmp_i.ensure(n)) return MVS_ERR_HIP;
+    if (op == MVS_PROBE_MATH) {
+        if (!in_f || !out_f) return MVS_ERR_ARG;
+        HIPCHK(hipMemcpyAsync(e->tmp_f_in.p, in_f, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    } else {
+        if (!in_rec) return MVS_ERR_ARG;
+        HIPCHK(hipMemcpyAsync(e->tmp_rec_in.p, in_rec, (size_t)n * sizeof(mvs_patch), hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemsetAsync(e->tmp_i.p, 0, (size_t)n * sizeof(int32_t), st));
+    const DParams p = current_params(e);
+    mvsk_probe(p, op, n, e->tmp_rec_in.p, e->tmp_f_in.p, e->tmp_rec_out.p, e->tmp_f_out.p, e->tmp_i.p, st);
+    if (out_rec && (op == MVS_PROBE_PREPROCESS || op == MVS_PROBE_REFINE || op == MVS_PROBE_POSTPROCESS))
+        HIPCHK(hipMemcpyAsync(out_rec, e->tmp_rec_out.p, (size_t)n * sizeof(mvs_patch), hipMemcpyDeviceToHost, st));
+    if (out_f && (op == MVS_PROBE_NCC || op == MVS_PROBE_COST || op == MVS_PROBE_MATH))
+        HIPCHK(hipMemcpyAsync(out_f, e->tmp_f_out.p, (size_t)nf_out * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (out_i) HIPCHK(hipMemcpyAsync(out_i, e->tmp_i.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    return MVS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,567 @@
+// mvs_kernels.hip -- HIP kernels of the MI355X PatchMatch-MVS engine (gfx950, wave64).
+#include <hip/hip_runtime.h>
+#include "mvs_device.cuh"
+#include "mvs_kernels.h"
+
+using namespace mvsdev;
+
+// =================================================================== K0: images
+// interleaved RGB (image/image.hpp:76) -> RGBA8 texels, one 32-bit load per texel
+__global__ void k_rgb_to_rgba(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = rgb + 3 * i;
+    out[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+__global__ void k_rgba_to_rgb(const uint32_t* __restrict__ in, uint8_t* __restrict__ rgb, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = in[i];
+    rgb[3 * i] = t & 255u; rgb[3 * i + 1] = (t >> 8) & 255u; rgb[3 * i + 2] = (t >> 16) & 255u;
+}
+// Image::buildImagePyramid, image.cpp:245-315 (filter 0): 4x4 [1 3 3 1]x[1 3 3 1]/64, stride 2, taps outside
+// the image dropped without renormalising (D8), round half up.
+__global__ void k_pyr_down(const uint32_t* __restrict__ src, int pw, int ph, uint32_t* __restrict__ dst, int w, int h) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const float base[4] = {1.0f, 3.0f, 3.0f, 1.0f};
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    for (int i = -1; i < 3; ++i) {
+        const int yt = 2 * y + i;
+        if (yt < 0 || ph - 1 < yt) continue;
+        for (int j = -1; j < 3; ++j) {
+            const int xt = 2 * x + j;
+            if (xt < 0 || pw - 1 < xt) continue;
+            const float m = (base[i + 1] * base[j + 1]) / 64.0f;
+            const uint32_t t = src[(size_t)yt * pw + xt];
+            c0 += m * (float)(t & 255u); c1 += m * (float)((t >> 8) & 255u); c2 += m * (float)((t >> 16) & 255u);
+        }
+    }
+    const uint32_t r = (uint8_t)((int)floorf(c0 + 0.5f)), g = (uint8_t)((int)floorf(c1 + 0.5f)), b = (uint8_t)((int)floorf(c2 + 0.5f));
+    dst[(size_t)y * w + x] = r | (g << 8) | (b << 16);
+}
+// Image::buildMaskPyramid, image.cpp:717-747 (indices clamped to the previous level)
+__global__ void k_mask_down(const uint8_t* __restrict__ src, int pw, int ph, uint8_t* __restrict__ dst, int w, int h) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int ys[2] = {2 * y, min(ph - 1, 2 * y + 1)}, xs[2] = {2 * x, min(pw - 1, 2 * x + 1)};
+    int inside = 0;
+    for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) inside += src[(size_t)ys[j] * pw + xs[i]] ? 1 : 0;
+    dst[(size_t)y * w + x] = inside > 0 ? 255 : 0;
+}
+__global__ void k_mask_binarise(uint8_t* m, int64_t n) {  // image.cpp:170-177
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) m[i] = m[i] > 127 ? 255 : 0;
+}
+
+// =================================================================== scan (exclusive, int32)
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 4
+__global__ void k_scan_block(const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t* __restrict__ block_sums, int64_t n_in) {
+    __shared__ int32_t s[SCAN_BLOCK];
+    const int64_t base = ((int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    int32_t v[SCAN_ITEMS], sum = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < n_in) ? in[base + k] : 0; sum += v[k]; }
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        int32_t t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int32_t excl = s[threadIdx.x] - sum;
+    for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k <= n_in) out[base + k] = excl; excl += v[k]; }
+    if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = s[threadIdx.x];
+}
+__global__ void k_scan_add(int32_t* __restrict__ out, const int32_t* __restrict__ block_offsets, int64_t n_out) {
+    const int64_t base = ((int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    const int32_t o = block_offsets[blockIdx.x];
+    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n_out) out[base + k] += o;
+}
+// out[i] = sum of in[0..i) for i in [0, n]; out[n] is the total (out has n+1 slots, in has n; in-place allowed).
+// tmp: block sums of every recursion level, at least n/512 + 64 ints.
+void launch_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, hipStream_t st) {
+    const int64_t per = (int64_t)SCAN_BLOCK * SCAN_ITEMS;
+    const int64_t nb = (n + 1 + per - 1) / per;
+    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, out, tmp, n);
+    if (nb > 1) {
+        int32_t* tmp2 = tmp + nb + 1;
+        launch_exclusive_scan(tmp, tmp, nb, tmp2, st);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, out, tmp, n + 1);
+    }
+}
+
+// =================================================================== index build
+// cnt[gcell] += 1 for every (patch, view) membership: PatchManager::addPatch, patch_manager.cpp:158-186
+__global__ void k_index_count(DParams prm, int32_t* __restrict__ cnt, int32_t* __restrict__ vcnt) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= prm.pool_n) return;
+    const DPatch* p = prm.pool + id;
+    if (!(p->flags & 1)) return;
+    const F4 coord = ld4(p->coord);
+    const int n = min(p->nimages, MVS_LISTCAP);
+    for (int i = 0; i < n; ++i) {
+        const DView* vw = prm.views + p->images[i];
+        int ix, iy;
+        cell_of(prm, vw, coord, ix, iy);
+        if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
+        atomicAdd(&cnt[vw->cell_base + iy * vw->gw + ix], 1);
+    }
+    if (vcnt) {
+        const int nv = min(p->nvimages, MVS_LISTCAP);
+        for (int i = 0; i < nv; ++i) {
+            const DView* vw = prm.views + p->vimages[i];
+            int ix, iy;
+            cell_of(prm, vw, coord, ix, iy);
+            if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
+            atomicAdd(&vcnt[vw->cell_base + iy * vw->gw + ix], 1);
+        }
+    }
+}
+__global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int32_t* __restrict__ cursor, int32_t* __restrict__ ids,
+                             const int32_t* __restrict__ vstart, int32_t* __restrict__ vcursor, int32_t* __restrict__ vids) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= prm.pool_n) return;
+    const DPatch* p = prm.pool + id;
+    if (!(p->flags & 1)) return;
+    const F4 coord = ld4(p->coord);
+    const int n = min(p->nimages, MVS_LISTCAP);
+    for (int i = 0; i < n; ++i) {
+        const DView* vw = prm.views + p->images[i];
+        int ix, iy;
+        cell_of(prm, vw, coord, ix, iy);
+        if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
+        const int g = vw->cell_base + iy * vw->gw + ix;
+        ids[start[g] + atomicAdd(&cursor[g], 1)] = (int32_t)id;
+    }
+    if (vstart) {
+        const int nv = min(p->nvimages, MVS_LISTCAP);
+        for (int i = 0; i < nv; ++i) {
+            const DView* vw = prm.views + p->vimages[i];
+            int ix, iy;
+            cell_of(prm, vw, coord, ix, iy);
+            if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
+            const int g = vw->cell_base + iy * vw->gw + ix;
+            vids[vstart[g] + atomicAdd(&vcursor[g], 1)] = (int32_t)id;
+        }
+    }
+}
+// PatchManager::sortPatches (descending NCC; ties by id) per cell, then the MAX_NUM_OF_PATCHES trim
+// (propagate.cpp:94-99,130-135): every cell decides on the same snapshot; a trimmed patch dies everywhere.
+__global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start, int32_t* __restrict__ ids, int do_trim,
+                                  unsigned long long* __restrict__ trimmed) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= prm.total_cells) return;
+    const int b = start[g], e = start[g + 1];
+    for (int i = b + 1; i < e; ++i) {
+        const int id = ids[i];
+        const float ncc = prm.pool[id].ncc;
+        int j = i - 1;
+        while (j >= b) {
+            const int o = ids[j];
+            const float on = prm.pool[o].ncc;
+            const bool o_before = (on != ncc) ? (on > ncc) : (o < id);
+            if (o_before) break;
+            ids[j + 1] = o;
+            --j;
+        }
+        ids[j + 1] = id;
+    }
+    if (do_trim) {
+        for (int k = b + prm.cap; k < e; ++k) {
+            const int old = atomicAnd(&prm.pool[ids[k]].flags, ~1);
+            if (old & 1) atomicAdd(trimmed, 1ull);
+        }
+    }
+}
+DEV uint32_t sortable_f32(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// PatchManager::updateDepthMaps, patch_manager.cpp:191-221, over the alive pool (Filter::setDepthMaps, filter.cpp:580-626)
+__global__ void k_depth_maps(DParams prm, unsigned long long* __restrict__ dp) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t id = t / prm.nviews;
+    const int image = (int)(t % prm.nviews);
+    if (id >= prm.pool_n) return;
+    const DPatch* p = prm.pool + id;
+    if (!(p->flags & 1)) return;
+    const F4 coord = ld4(p->coord);
+    const DView* vw = prm.views + image;
+    const F3 ic = project(vw, coord, prm.level);
+    const float fx = ic.x / (float)prm.csize, fy = ic.y / (float)prm.csize;
+    const int xs[2] = {(int)floorf(fx), (int)ceilf(fx)}, ys[2] = {(int)floorf(fy), (int)ceilf(fy)};
+    const float depth = dot4(ld4(vw->oaxis), coord);
+    const unsigned long long key = ((unsigned long long)sortable_f32(depth) << 32) | (unsigned long long)(uint32_t)id;
+    for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) {
+        if (xs[i] < 0 || vw->gw <= xs[i] || ys[j] < 0 || vw->gh <= ys[j]) continue;
+        if (i == 1 && xs[1] == xs[0]) continue;  // same cell twice: idempotent, skip
+        if (j == 1 && ys[1] == ys[0]) continue;
+        atomicMin(&dp[vw->cell_base + ys[j] * vw->gw + xs[i]], key);
+    }
+}
+// best-NCC patch per cell among those whose reference view is `view` (parity artefact)
+__global__ void k_best_ncc_map(DParams prm, int view, unsigned long long* __restrict__ best) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= prm.pool_n) return;
+    const DPatch* p = prm.pool + id;
+    if (!(p->flags & 1) || p->nimages == 0 || p->images[0] != view) return;
+    const DView* vw = prm.views + view;
+    int ix, iy;
+    cell_of(prm, vw, ld4(p->coord), ix, iy);
+    if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) return;
+    const unsigned long long key = ((unsigned long long)sortable_f32(p->ncc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)id);
+    atomicMax(&best[iy * vw->gw + ix], key);
+}
+__global__ void k_map_extract(DParams prm, int view, int kind, const unsigned long long* __restrict__ sel, float* __restrict__ depth,
+                              float* __restrict__ normal, int32_t* __restrict__ ids, int ncells) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    const unsigned long long k = sel[c];
+    const bool empty = kind == 0 ? (k == ~0ull) : (k == 0ull);
+    if (empty) {
+        depth[c] = __int_as_float(0x7fc00000);
+        normal[3 * c] = normal[3 * c + 1] = normal[3 * c + 2] = __int_as_float(0x7fc00000);
+        ids[c] = -1;
+        return;
+    }
+    const uint32_t id = kind == 0 ? (uint32_t)(k & 0xffffffffull) : 0xffffffffu - (uint32_t)(k & 0xffffffffull);
+    const DPatch* p = prm.pool + id;
+    depth[c] = dot4(ld4((prm.views + view)->oaxis), ld4(p->coord));
+    normal[3 * c] = p->normal[0]; normal[3 * c + 1] = p->normal[1]; normal[3 * c + 2] = p->normal[2];
+    ids[c] = (int32_t)id;
+}
+
+// PatchManager::sortPatches head (patch_manager.cpp:411-415): patches with m_ncc < 0 get their score.
+__global__ __launch_bounds__(64) void k_fill_ncc(DParams prm, unsigned long long* evals) {
+    const int64_t id = blockIdx.x;
+    DPatch* p = prm.pool + id;
+    if (!(p->flags & 1) || !(p->ncc < 0.0f)) return;
+    WaveCtx wc = make_wave_ctx(prm);
+    Cand c;
+    load_cand(p, wc, c);
+    const float ncc = compute_ncc(prm, wc, c.coord, c.normal, c.img, c.nimg);
+    if (wc.lane == 0) { p->ncc = ncc; atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
+}
+
+// =================================================================== K4: the sweep
+// One wavefront per destination cell of the pass colour.  Propagate::propagatePmImage (propagate.cpp:72-124)
+// turned inside out: the cell gathers from the cell above/below and the cell beside it, in the order the
+// raster sweep would reach them, and runs Propagate::propagatePatch (propagate.cpp:126-218) on its own list.
+DEV bool rank_before(float na, int a, float nb, int b) { return (na != nb) ? (na > nb) : (a < b); }
+
+__global__ __launch_bounds__(64) void k_sweep(DParams prm, SweepArgs a) {
+    __shared__ int s_scratch[192];
+    extern __shared__ float s_texs[];
+    // XCD-aware job order: blocks are dealt round-robin over the 8 XCDs, so block b works on job
+    // (b % 8) * chunk + b / 8 and each XCD's L2 sees one contiguous band of cells.
+    const int64_t chunk = (a.njobs + 7) / 8;
+    const int64_t job = (int64_t)(blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if (job >= a.njobs) return;
+    int s = 0;
+    while (s + 1 < a.nsweep_views && job >= a.job_base[s + 1]) ++s;
+    const int v = a.sweep_views[s];
+    const DView* vw = prm.views + v;
+    const int gw = vw->gw, gh = vw->gh, halfw = (gw + 1) / 2;
+    const int local = (int)(job - a.job_base[s]);
+    const int cy = local / halfw, bx = local % halfw;
+    const int cx = 2 * bx + ((a.colour + cy) & 1);
+    WaveCtx wc = make_wave_ctx(prm);
+    if (wc.lane == 0) a.job_nstage[job] = 0;
+    if (cx >= gw || cy >= gh) return;
+    const int cell = cy * gw + cx;
+    const int inc = a.inc;
+    const int sxs[2] = {cx, cx - inc}, sys[2] = {cy - inc, cy};
+    // any source at all?
+    bool has = false;
+    for (int k = 0; k < 2; ++k) {
+        if (sxs[k] < 0 || gw <= sxs[k] || sys[k] < 0 || gh <= sys[k]) continue;
+        const int g = vw->cell_base + sys[k] * gw + sxs[k];
+        has |= prm.csr_start[g + 1] > prm.csr_start[g];
+    }
+    if (!has) return;
+
+    const int tstride = (prm.wsz + 3) & ~3;
+    unsigned n_cand = 0, n_pref = 0, n_patch = 0, n_f0 = 0, n_f1 = 0, n_ins = 0, n_rep = 0;
+    // live list of this cell as view-lane arrays: lane k holds entry k (sorted: ncc desc, id asc)
+    int L_id = -1;
+    float L_ncc = 0.0f;
+    int L_n = 0;
+    {
+        const int g = vw->cell_base + cell;
+        const int b = prm.csr_start[g], e = prm.csr_start[g + 1];
+        for (int k = b; k < e; ++k) {
+            const int id = prm.csr_ids[k];
+            const DPatch* p = prm.pool + id;
+            if (!(p->flags & 1)) continue;
+            if (wc.lane == L_n) { L_id = id; L_ncc = p->ncc; }
+            ++L_n;
+        }
+    }
+    int ns = 0;  // staged records of this job
+    const float icx = (float)(prm.csize * (2 * cx + 1) - 1) / 2.0f, icy = (float)(prm.csize * (2 * cy + 1) - 1) / 2.0f;
+
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        if (sxs[sidx] < 0 || gw <= sxs[sidx] || sys[sidx] < 0 || gh <= sys[sidx]) continue;
+        const int g = vw->cell_base + sys[sidx] * gw + sxs[sidx];
+        const int sb = prm.csr_start[g], se = prm.csr_start[g + 1];
+        int nalive = 0;
+        for (int k = sb; k < se; ++k) {
+            const int sid = prm.csr_ids[k];
+            const DPatch* sp = prm.pool + sid;
+            if (!(sp->flags & 1)) continue;
+            const int n = nalive++;
+            if (sp->images[0] != v) continue;
+            Cand src;
+            load_cand(sp, wc, src);
+            const int srcslot = sidx * prm.cap + n;
+            // ---- Propagate::propagatePatch, propagate.cpp:153-213
+            for (int it = 0; it < prm.max_propag; ++it) {
+                const int np = L_n;
+                const uint32_t k0 = (uint32_t)a.iter, k1 = (uint32_t)v, k2 = (uint32_t)cell, k3 = (uint32_t)(srcslot * 16 + it);
+                Cand c;
+                int worst = -1;
+                float worst_ncc = 0.0f;
+                F3 ic;
+                if (np < prm.cap) {
+                    const float ra = rng_uniform(prm.seed, k0, k1, k2, k3, 0) * (float)prm.csize;
+                    const float rb = rng_uniform(prm.seed, k0, k1, k2, k3, 1) * (float)prm.csize;
+                    ic = {icx + ra, icy + rb, 1.0f};
+                } else {
+                    worst = rli(L_id, prm.cap - 1);
+                    worst_ncc = rlf(L_ncc, prm.cap - 1);
+                    const DPatch* wp = worst >= MVS_NEWBASE ? a.staging + (worst - MVS_NEWBASE) : prm.pool + worst;
+                    ic = project(vw, ld4(wp->coord), prm.level);
+                }
+                if (!generate_patch(prm, wc, s_scratch, src, ic, c)) continue;
+                ++n_cand;
+                if (np >= prm.cap && c.ncc < worst_ncc) { ++n_pref; continue; }
+                ++n_patch;
+                if (pre_process(prm, wc, s_scratch, c) == -1) { ++n_f0; continue; }
+                refine_patch(prm, wc, c, k0, k1, k2, k3);
+                if (post_process(prm, wc, s_scratch, s_texs, tstride, c) == -1) { ++n_f1; continue; }
+                // staging slot for the accepted patch
+                unsigned long long slot64 = 0;
+                if (wc.lane == 0) slot64 = atomicAdd(a.stage_counter, 1ull);
+                const int64_t slot = ((int64_t)rfl((int)(slot64 >> 32)) << 32) | (uint32_t)rfl((int)(slot64 & 0xffffffffull));
+                if (slot >= a.staging_cap || ns >= a.maxstage) {
+                    if (wc.lane == 0) atomicOr(a.error_flag, 1);
+                    continue;
+                }
+                if (np == prm.cap) {  // removePatch(worst), propagate.cpp:198-201
+                    if (wc.lane == 0) {
+                        if (worst >= MVS_NEWBASE) a.staging[worst - MVS_NEWBASE].flags &= ~1;
+                        else a.kill[worst] = 1;
+                    }
+                    --L_n;
+                    ++n_rep;
+                } else ++n_ins;
+                store_cand(a.staging + slot, wc, c, 1 | (v << 8), cell);
+                if (wc.lane == 0) a.job_stage[job * a.maxstage + ns] = (int32_t)slot;
+                ++ns;
+                // PatchManager::addPatch into this cell's own list if the patch lands here
+                const bool lands = ballot(wc.lane < c.nimg && c.img == v && c.gy * gw + c.gx == cell) != 0ull;
+                if (lands) {
+                    const int nid = MVS_NEWBASE + (int)slot;
+                    const int pos = __popcll(ballot(wc.lane < L_n && rank_before(L_ncc, L_id, c.ncc, nid)));
+                    const int up_id = __shfl_up(L_id, 1);
+                    const float up_ncc = __shfl_up(L_ncc, 1);
+                    if (wc.lane > pos) { L_id = up_id; L_ncc = up_ncc; }
+                    if (wc.lane == pos) { L_id = nid; L_ncc = c.ncc; }
+                    ++L_n;
+                }
+            }
+        }
+    }
+    if (wc.lane == 0) {
+        a.job_nstage[job] = ns;
+        DCounters* C = a.counters;
+        if (n_cand) atomicAdd(&C->candidates, (unsigned long long)n_cand);
+        if (n_pref) atomicAdd(&C->prefiltered, (unsigned long long)n_pref);
+        if (n_patch) atomicAdd(&C->patches, (unsigned long long)n_patch);
+        if (n_f0) atomicAdd(&C->fail0, (unsigned long long)n_f0);
+        if (n_f1) atomicAdd(&C->fail1, (unsigned long long)n_f1);
+        if (n_ins) atomicAdd(&C->inserted, (unsigned long long)n_ins);
+        if (n_rep) atomicAdd(&C->replaced, (unsigned long long)n_rep);
+        if (wc.evals) atomicAdd(&C->evals, (unsigned long long)wc.evals);
+        if (wc.view_evals) atomicAdd(&C->view_evals, (unsigned long long)wc.view_evals);
+    }
+}
+
+// =================================================================== commit
+// alive staged records per job -> cnt[job]
+__global__ void k_commit_count(SweepArgs a, int32_t* __restrict__ cnt) {
+    const int64_t job = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= a.njobs) return;
+    const int ns = a.job_nstage[job];
+    int c = 0;
+    for (int k = 0; k < ns; ++k) c += a.staging[a.job_stage[job * a.maxstage + k]].flags & 1;
+    cnt[job] = c;
+}
+// copy alive staged records to dst[base[job] + r] in creation order: global order (view, cell, sequence)
+__global__ void k_commit_copy(SweepArgs a, const int32_t* __restrict__ base, DPatch* __restrict__ dst, int64_t dst_cap, int32_t* __restrict__ per_view,
+                              int keep_key) {
+    const int64_t job = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= a.njobs) return;
+    const int ns = a.job_nstage[job];
+    int r = 0;
+    for (int k = 0; k < ns; ++k) {
+        const DPatch* sp = a.staging + a.job_stage[job * a.maxstage + k];
+        if (!(sp->flags & 1)) continue;
+        const int64_t o = (int64_t)base[job] + r++;
+        if (o >= dst_cap) { atomicOr(a.error_flag, 2); return; }
+        const uint4* s4 = reinterpret_cast<const uint4*>(sp);
+        uint4* d4 = reinterpret_cast<uint4*>(dst + o);
+        for (int w = 0; w < 8; ++w) d4[w] = s4[w];
+        if (per_view) atomicAdd(&per_view[(sp->flags >> 8) & 0xff], 1);
+        if (!keep_key) { dst[o].flags = 1; dst[o].id = 0; }
+    }
+}
+__global__ void k_kill_count(const uint8_t* __restrict__ kill, int64_t n, int32_t* __restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = kill[i] ? 1 : 0;
+}
+__global__ void k_kill_export(const uint8_t* __restrict__ kill, int64_t n, const int32_t* __restrict__ base, int32_t* __restrict__ ids, int64_t cap) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && kill[i] && base[i] < cap) ids[base[i]] = (int32_t)i;
+}
+__global__ void k_apply_kill_flags(DPatch* pool, uint8_t* kill, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && kill[i]) { pool[i].flags &= ~1; kill[i] = 0; }
+}
+__global__ void k_apply_kill_ids(DPatch* pool, const int32_t* __restrict__ ids, int64_t n, int64_t pool_n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ids[i] >= 0 && ids[i] < pool_n) pool[ids[i]].flags &= ~1;
+}
+__global__ void k_append_records(DPatch* pool, int64_t pool_n, const DPatch* __restrict__ recs, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* s4 = reinterpret_cast<const uint4*>(recs + i);
+    uint4* d4 = reinterpret_cast<uint4*>(pool + pool_n + i);
+    for (int w = 0; w < 8; ++w) d4[w] = s4[w];
+    pool[pool_n + i].flags = 1;
+    pool[pool_n + i].id = 0;
+}
+__global__ void k_alive_count(const DPatch* __restrict__ pool, int64_t n, int32_t* __restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = pool[i].flags & 1;
+}
+__global__ void k_alive_gather(const DPatch* __restrict__ pool, int64_t n, const int32_t* __restrict__ base, DPatch* __restrict__ out, int64_t cap) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !(pool[i].flags & 1) || base[i] >= cap) return;
+    const uint4* s4 = reinterpret_cast<const uint4*>(pool + i);
+    uint4* d4 = reinterpret_cast<uint4*>(out + base[i]);
+    for (int w = 0; w < 8; ++w) d4[w] = s4[w];
+    out[base[i]].id = (int32_t)i;
+}
+
+// =================================================================== probes (single functions, batched)
+__global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, const DPatch* __restrict__ in, const float* __restrict__ in_f,
+                                              DPatch* __restrict__ out, float* __restrict__ out_f, int32_t* __restrict__ out_i) {
+    __shared__ int s_scratch[192];
+    extern __shared__ float s_texs[];
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    WaveCtx wc = make_wave_ctx(prm);
+    const int tstride = (prm.wsz + 3) & ~3;
+    if (op == 5) {  // MVS_PROBE_MATH
+        if (wc.lane == 0) {
+            const float x = in_f[i];
+            out_f[5 * i] = pm_sinf(x); out_f[5 * i + 1] = pm_cosf(x); out_f[5 * i + 2] = pm_asinf(x); out_f[5 * i + 3] = pm_acosf(x);
+            out_f[5 * i + 4] = pm_atanf(x);
+        }
+        return;
+    }
+    Cand c;
+    load_cand(in + i, wc, c);
+    if (op == 0) {  // MVS_PROBE_NCC
+        const float ncc = compute_ncc(prm, wc, c.coord, c.normal, c.img, c.nimg);
+        if (wc.lane == 0) out_f[i] = ncc;
+    } else if (op == 1) {
+        const int f = pre_process(prm, wc, s_scratch, c);
+        store_cand(out + i, wc, c, 1, (int)i);
+        if (wc.lane == 0) out_i[i] = f;
+    } else if (op == 2) {
+        refine_patch(prm, wc, c, 0u, 0u, (uint32_t)i, 0u);
+        store_cand(out + i, wc, c, 1, (int)i);
+    } else if (op == 3) {
+        const int f = post_process(prm, wc, s_scratch, s_texs, tstride, c);
+        store_cand(out + i, wc, c, 1, (int)i);
+        if (wc.lane == 0) out_i[i] = f;
+    } else if (op == 4) {
+        RefineCtx rc;
+        rc.center = c.coord; rc.ref = rli(c.img, 0);
+        rc.ray = sub4(c.coord, ld4((prm.views + rc.ref)->center));
+        rc.ray = div4(rc.ray, norm4(rc.ray));
+        rc.dscale = c.dscale; rc.ascale = prm.ascaleConst;
+        float x[3];
+        encode(prm, rc, c.coord, c.normal, x);
+        const double f = cost_func(prm, wc, rc, c.img, c.nimg, x);
+        if (wc.lane == 0) out_f[i] = (float)f;
+    }
+}
+
+// =================================================================== host-callable launchers
+static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+void mvsk_rgb_to_rgba(const uint8_t* rgb, uint32_t* out, int64_t n, hipStream_t st) { hipLaunchKernelGGL(k_rgb_to_rgba, dim3(nblk(n, 256)), dim3(256), 0, st, rgb, out, n); }
+void mvsk_rgba_to_rgb(const uint32_t* in, uint8_t* rgb, int64_t n, hipStream_t st) { hipLaunchKernelGGL(k_rgba_to_rgb, dim3(nblk(n, 256)), dim3(256), 0, st, in, rgb, n); }
+void mvsk_pyr_down(const uint32_t* src, int pw, int ph, uint32_t* dst, int w, int h, hipStream_t st) {
+    hipLaunchKernelGGL(k_pyr_down, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, st, src, pw, ph, dst, w, h);
+}
+void mvsk_mask_down(const uint8_t* src, int pw, int ph, uint8_t* dst, int w, int h, hipStream_t st) {
+    hipLaunchKernelGGL(k_mask_down, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, st, src, pw, ph, dst, w, h);
+}
+void mvsk_mask_binarise(uint8_t* m, int64_t n, hipStream_t st) { hipLaunchKernelGGL(k_mask_binarise, dim3(nblk(n, 256)), dim3(256), 0, st, m, n); }
+void mvsk_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, hipStream_t st) { launch_exclusive_scan(in, out, n, tmp, st); }
+void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, cnt, vcnt);
+}
+void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, int32_t* ids, const int32_t* vstart, int32_t* vcursor, int32_t* vids, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, start, cursor, ids, vstart, vcursor, vids);
+}
+void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, int32_t* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_sort_trim, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, do_trim, trimmed);
+}
+void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, hipStream_t st) {
+    const int64_t n = prm.pool_n * prm.nviews;
+    if (n > 0) hipLaunchKernelGGL(k_depth_maps, dim3(nblk(n, 256)), dim3(256), 0, st, prm, dp);
+}
+void mvsk_best_ncc_map(const DParams& prm, int view, unsigned long long* best, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_best_ncc_map, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, view, best);
+}
+void mvsk_map_extract(const DParams& prm, int view, int kind, const unsigned long long* sel, float* depth, float* normal, int32_t* ids, int ncells, hipStream_t st) {
+    hipLaunchKernelGGL(k_map_extract, dim3(nblk(ncells, 256)), dim3(256), 0, st, prm, view, kind, sel, depth, normal, ids, ncells);
+}
+void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_fill_ncc, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, evals);
+}
+size_t mvsk_sweep_lds_bytes(const DParams& prm) { return (size_t)MVS_LISTCAP * 3 * ((prm.wsz + 3) & ~3) * sizeof(float); }
+void mvsk_sweep(const DParams& prm, const SweepArgs& a, hipStream_t st) {
+    if (a.njobs <= 0) return;
+    const int64_t chunk = (a.njobs + 7) / 8;
+    hipLaunchKernelGGL(k_sweep, dim3((unsigned)(chunk * 8)), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, a);
+}
+void mvsk_commit_count(const SweepArgs& a, int32_t* cnt, hipStream_t st) { hipLaunchKernelGGL(k_commit_count, dim3(nblk(a.njobs, 256)), dim3(256), 0, st, a, cnt); }
+void mvsk_commit_copy(const SweepArgs& a, const int32_t* base, DPatch* dst, int64_t dst_cap, int32_t* per_view, int keep_key, hipStream_t st) {
+    hipLaunchKernelGGL(k_commit_copy, dim3(nblk(a.njobs, 256)), dim3(256), 0, st, a, base, dst, dst_cap, per_view, keep_key);
+}
+void mvsk_kill_count(const uint8_t* kill, int64_t n, int32_t* cnt, hipStream_t st) { if (n > 0) hipLaunchKernelGGL(k_kill_count, dim3(nblk(n, 256)), dim3(256), 0, st, kill, n, cnt); }
+void mvsk_kill_export(const uint8_t* kill, int64_t n, const int32_t* base, int32_t* ids, int64_t cap, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_kill_export, dim3(nblk(n, 256)), dim3(256), 0, st, kill, n, base, ids, cap);
+}
+void mvsk_apply_kill_flags(DPatch* pool, uint8_t* kill, int64_t n, hipStream_t st) { if (n > 0) hipLaunchKernelGGL(k_apply_kill_flags, dim3(nblk(n, 256)), dim3(256), 0, st, pool, kill, n); }
+void mvsk_apply_kill_ids(DPatch* pool, const int32_t* ids, int64_t n, int64_t pool_n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_apply_kill_ids, dim3(nblk(n, 256)), dim3(256), 0, st, pool, ids, n, pool_n);
+}
+void mvsk_append_records(DPatch* pool, int64_t pool_n, const DPatch* recs, int64_t n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_append_records, dim3(nblk(n, 256)), dim3(256), 0, st, pool, pool_n, recs, n);
+}
+void mvsk_alive_count(const DPatch* pool, int64_t n, int32_t* cnt, hipStream_t st) { if (n > 0) hipLaunchKernelGGL(k_alive_count, dim3(nblk(n, 256)), dim3(256), 0, st, pool, n, cnt); }
+void mvsk_alive_gather(const DPatch* pool, int64_t n, const int32_t* base, DPatch* out, int64_t cap, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_alive_gather, dim3(nblk(n, 256)), dim3(256), 0, st, pool, n, base, out, cap);
+}
+void mvsk_probe(const DParams& prm, int op, int64_t n, const DPatch* in, const float* in_f, DPatch* out, float* out_f, int32_t* out_i, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_probe, dim3((unsigned)n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, op, n, in, in_f, out, out_f, out_i);
+}

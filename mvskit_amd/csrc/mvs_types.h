@@ -1,0 +1,83 @@
+// mvs_types.h -- device-side data layout of the MI355X PatchMatch-MVS engine (internal).
+#pragma once
+#include <stdint.h>
+
+#define MVS_WAVE 64
+#define MVS_MAXLEV 7       // level (<=4) + 3 pyramid levels (pmmvps.cpp:36)
+#define MVS_LISTCAP 16     // m_images / m_vimages are truncated to 16 views
+#define MVS_MAXI 32        // storage in the record
+#define MVS_MAXVIEWS 64    // one lane per view in the per-view phases
+#define MVS_CAPMAX 32      // MAX_NUM_OF_PATCHES = max_propag * csize^2 <= 32
+#define MVS_NEWBASE 0x40000000  // ids >= NEWBASE: staged record NEWBASE + slot
+
+// Patch record (pmmvps/patch.hpp:33-66); same bytes as mvs_patch in include/mvskit_engine.h.
+struct DPatch {
+    float coord[4];
+    float normal[4];
+    float ncc, dscale, ascale, tmp;
+    int32_t nimages, nvimages, flags, id;
+    uint8_t images[MVS_MAXI];
+    uint8_t vimages[MVS_MAXI];
+};
+static_assert(sizeof(DPatch) == 128, "record is 128 bytes");
+
+// One view resident in HBM: camera (image/camera.cpp:65-100), Optim axes (optim.cpp:43-65), pyramid
+// (image/image.cpp:245-315) as RGBA8 texels (one 32-bit load per texel), mask at m_level, grid size.
+struct DView {
+    float P[MVS_MAXLEV][12];
+    float Minv[9];  // inverse of the 3x3 block of P[level]
+    float center[4];
+    float oaxis[4];
+    float xaxis[3], yaxis[3], zaxis[3];
+    float ipscale;
+    int32_t W[MVS_MAXLEV], H[MVS_MAXLEV];
+    const uint32_t* img[MVS_MAXLEV];
+    const uint8_t* mask;  // level m_level, or null
+    int32_t gw, gh;
+    int32_t cell_base;  // offset of this view's cells in the concatenated per-cell arrays
+    int32_t pad;
+};
+
+// Kernel-constant parameters (Option + PmMvps thresholds, pmmvps.cpp:18-68).
+struct DParams {
+    int32_t nviews, level, csize, wsize, wsz, minImageNum, tau, cap, max_propag, depth, enable_check;
+    uint32_t seed;
+    int32_t refine_steps;
+    float rd0, ra0;
+    float nccThreshold, nccThresholdBefore;
+    float cosAngle0, cosAngle1, cosMinAngle, cosMaxAngle, cosNeighborTypo, cosNeighbor120;
+    float sortThreshold, ascaleConst, neighborThreshold, neighborThreshold1, quadThreshold;
+    int32_t total_cells;
+    const DView* views;
+    DPatch* pool;
+    int64_t pool_n;
+    // index (rebuilt every pass): per concatenated cell [start, start+cnt) into csr_ids, sorted (ncc desc, id asc)
+    const int32_t* csr_start;
+    const int32_t* csr_ids;
+    const int32_t* vcsr_start;
+    const int32_t* vcsr_ids;
+    const unsigned long long* dpgrid;  // (sortable depth << 32 | id), ~0ull = m_MAXDEPTH
+};
+
+struct DCounters {
+    unsigned long long candidates, prefiltered, patches, fail0, fail1, inserted, replaced, evals, view_evals, trimmed;
+};
+
+// Arguments of one sweep launch (one colour pass over the owned views).
+struct SweepArgs {
+    int32_t iter, inc, colour;
+    int32_t nsweep_views;
+    int32_t sweep_views[MVS_MAXVIEWS];
+    int32_t job_base[MVS_MAXVIEWS];  // first job id of each swept view
+    int32_t halfw_max, gh_max;
+    int64_t njobs;
+    DPatch* staging;
+    int64_t staging_cap;
+    unsigned long long* stage_counter;
+    int32_t* job_stage;   // [njobs][maxstage] staging slots in creation order
+    int32_t* job_nstage;  // [njobs]
+    int32_t maxstage;
+    uint8_t* kill;        // [pool_cap]
+    DCounters* counters;
+    int32_t* error_flag;
+};

@@ -1,0 +1,250 @@
+"""ctypes binding of the C ABI in include/mvskit_engine.h.
+
+There is no CPU path: if the HIP library is missing or no GPU is visible, creating an Engine raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+from .synth import MAX_IMAGES, PATCH_DTYPE  # noqa: F401  (PATCH_DTYPE mirrors mvs_patch)
+
+PROBE_NCC, PROBE_PREPROCESS, PROBE_REFINE, PROBE_POSTPROCESS, PROBE_COST, PROBE_MATH = range(6)
+
+#: every symbol include/mvskit_engine.h declares
+EXPORTS = [
+    "mvs_last_error", "mvs_device_count", "mvs_default_config", "mvs_engine_create", "mvs_engine_destroy",
+    "mvs_engine_set_views", "mvs_engine_grid_dims", "mvs_engine_get_pyramid", "mvs_engine_set_thresholds",
+    "mvs_engine_get_thresholds", "mvs_engine_update_threshold", "mvs_engine_upload_patches",
+    "mvs_engine_clear_patches", "mvs_engine_num_patches", "mvs_engine_download_patches", "mvs_engine_propagate",
+    "mvs_engine_pass", "mvs_engine_export_counts", "mvs_engine_export_device", "mvs_engine_commit_device",
+    "mvs_engine_commit_local", "mvs_engine_depth_normal_map", "mvs_engine_probe", "mvs_engine_last_timing",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("nviews", C.c_int32), ("level", C.c_int32), ("csize", C.c_int32), ("wsize", C.c_int32),
+                ("minImageNum", C.c_int32), ("max_propag", C.c_int32), ("nccThreshold", C.c_float),
+                ("maxAngleThreshold", C.c_float), ("quadThreshold", C.c_float), ("depth", C.c_int32),
+                ("seed", C.c_uint32), ("refine_steps", C.c_int32), ("refine_rd0", C.c_float), ("refine_ra0", C.c_float),
+                ("enable_check", C.c_int32), ("view_begin", C.c_int32), ("view_stride", C.c_int32),
+                ("device", C.c_int32), ("max_patches", C.c_int64)]
+
+
+class ViewDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("P", C.c_float * 12), ("rgb", C.c_void_p),
+                ("mask", C.c_void_p)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("candidates", "prefiltered", "patches", "fail0", "fail1", "inserted",
+                                         "replaced", "evals", "view_evals", "trimmed")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class Timing(C.Structure):
+    _fields_ = [("index_ms", C.c_float), ("sweep_ms", C.c_float), ("commit_ms", C.c_float), ("sweep_launches", C.c_int32)]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libmvskit_engine.so (built in-tree by mvskit_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(f"{LIB_PATH} is missing: run `python -m mvskit_amd.build` (the engine has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.mvs_last_error.restype = C.c_char_p
+    L.mvs_device_count.restype = C.c_int
+    L.mvs_default_config.argtypes = [C.POINTER(Config)]
+    L.mvs_engine_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.mvs_engine_destroy.argtypes = [vp]
+    L.mvs_engine_set_views.argtypes = [vp, C.c_int, C.POINTER(ViewDesc)]
+    L.mvs_engine_grid_dims.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mvs_engine_get_pyramid.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mvs_engine_set_thresholds.argtypes = [vp, C.c_float, C.c_float, C.c_int]
+    L.mvs_engine_get_thresholds.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.mvs_engine_update_threshold.argtypes = [vp]
+    L.mvs_engine_upload_patches.argtypes = [vp, C.c_int64, vp]
+    L.mvs_engine_clear_patches.argtypes = [vp]
+    L.mvs_engine_num_patches.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.mvs_engine_download_patches.argtypes = [vp, C.c_int64, vp, C.POINTER(C.c_int64)]
+    L.mvs_engine_propagate.argtypes = [vp, C.c_int, C.POINTER(Counters)]
+    L.mvs_engine_pass.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Counters)]
+    L.mvs_engine_export_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]
+    L.mvs_engine_export_device.argtypes = [vp, vp, C.c_int64, vp, C.c_int64]
+    L.mvs_engine_commit_device.argtypes = [vp, vp, C.c_int64, vp, C.c_int64]
+    L.mvs_engine_commit_local.argtypes = [vp]
+    L.mvs_engine_depth_normal_map.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.mvs_engine_probe.argtypes = [vp, C.c_int, C.c_int64, vp, vp, vp, vp, vp]
+    L.mvs_engine_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    """One PmMvps instance whose Propagate::run lives on an MI355X (pmmvps/pmmvps.cpp:76-114)."""
+
+    def __init__(self, nviews, **kw):
+        self.L = load_library()
+        self.cfg = Config()
+        self.L.mvs_default_config(C.byref(self.cfg))
+        self.cfg.nviews = nviews
+        for k, v in kw.items():
+            if not hasattr(self.cfg, k):
+                raise AttributeError(k)
+            setattr(self.cfg, k, v)
+        self.h = C.c_void_p()
+        self._check(self.L.mvs_engine_create(C.byref(self.cfg), C.byref(self.h)))
+        self._keep = None
+
+    def _check(self, status):
+        if status != 0:
+            raise EngineError(f"mvskit engine error {status}: {self.L.mvs_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.mvs_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- views
+    def set_scene(self, scene, masks=None):
+        n = scene.nviews
+        descs = (ViewDesc * n)()
+        keep = []
+        for v in range(n):
+            img = np.ascontiguousarray(scene.images[v], dtype=np.uint8)
+            keep.append(img)
+            descs[v].width, descs[v].height = scene.W, scene.H
+            P = np.ascontiguousarray(scene.P[v], dtype=np.float32).ravel()
+            for k in range(12):
+                descs[v].P[k] = float(P[k])
+            descs[v].rgb = img.ctypes.data
+            descs[v].mask = None
+            if masks is not None:
+                m = np.ascontiguousarray(masks[v], dtype=np.uint8)
+                keep.append(m)
+                descs[v].mask = m.ctypes.data
+        self._check(self.L.mvs_engine_set_views(self.h, n, descs))
+
+    def grid_dims(self, v):
+        gw, gh = C.c_int(), C.c_int()
+        self._check(self.L.mvs_engine_grid_dims(self.h, v, C.byref(gw), C.byref(gh)))
+        return gw.value, gh.value
+
+    def pyramid(self, v, level):
+        w, h = C.c_int(), C.c_int()
+        self._check(self.L.mvs_engine_get_pyramid(self.h, v, level, None, C.byref(w), C.byref(h)))
+        out = np.empty((h.value, w.value, 3), dtype=np.uint8)
+        self._check(self.L.mvs_engine_get_pyramid(self.h, v, level, _ptr(out), C.byref(w), C.byref(h)))
+        return out
+
+    def set_thresholds(self, ncc, before, depth):
+        self._check(self.L.mvs_engine_set_thresholds(self.h, ncc, before, depth))
+
+    def thresholds(self):
+        a, b, d = C.c_float(), C.c_float(), C.c_int()
+        self._check(self.L.mvs_engine_get_thresholds(self.h, C.byref(a), C.byref(b), C.byref(d)))
+        return a.value, b.value, d.value
+
+    def update_threshold(self):
+        self._check(self.L.mvs_engine_update_threshold(self.h))
+
+    # ---- patches
+    def upload_patches(self, recs):
+        recs = np.ascontiguousarray(recs, dtype=PATCH_DTYPE)
+        self._check(self.L.mvs_engine_upload_patches(self.h, recs.shape[0], _ptr(recs)))
+
+    add_patches = upload_patches
+
+    def clear_patches(self):
+        self._check(self.L.mvs_engine_clear_patches(self.h))
+
+    def num_patches(self):
+        n = C.c_int64()
+        self._check(self.L.mvs_engine_num_patches(self.h, C.byref(n)))
+        return n.value
+
+    def patches(self):
+        n = C.c_int64()
+        self._check(self.L.mvs_engine_download_patches(self.h, 0, None, C.byref(n)))
+        out = np.zeros(n.value, dtype=PATCH_DTYPE)
+        if n.value:
+            self._check(self.L.mvs_engine_download_patches(self.h, n.value, _ptr(out), C.byref(n)))
+        return out
+
+    # ---- the hot path
+    def propagate(self, it):
+        c = Counters()
+        self._check(self.L.mvs_engine_propagate(self.h, it, C.byref(c)))
+        return c.as_dict()
+
+    def engine_pass(self, it, p):
+        c = Counters()
+        self._check(self.L.mvs_engine_pass(self.h, it, p, C.byref(c)))
+        return c.as_dict()
+
+    def export_counts(self):
+        a, b = C.c_int64(), C.c_int64()
+        pv = np.zeros(self.cfg.nviews, dtype=np.int32)
+        self._check(self.L.mvs_engine_export_counts(self.h, C.byref(a), C.byref(b), _ptr(pv)))
+        return a.value, b.value, pv
+
+    def export_device(self, new_ptr, cap_new, kill_ptr, cap_kill):
+        self._check(self.L.mvs_engine_export_device(self.h, new_ptr, cap_new, kill_ptr, cap_kill))
+
+    def commit_device(self, new_ptr, n_new, kill_ptr, n_kill):
+        self._check(self.L.mvs_engine_commit_device(self.h, new_ptr, n_new, kill_ptr, n_kill))
+
+    def commit_local(self):
+        self._check(self.L.mvs_engine_commit_local(self.h))
+
+    def timing(self):
+        t = Timing()
+        self._check(self.L.mvs_engine_last_timing(self.h, C.byref(t)))
+        return {"index_ms": t.index_ms, "sweep_ms": t.sweep_ms, "commit_ms": t.commit_ms, "sweep_launches": t.sweep_launches}
+
+    def depth_normal_map(self, view, kind):
+        gw, gh = self.grid_dims(view)
+        d = np.zeros((gh, gw), np.float32)
+        n = np.zeros((gh, gw, 3), np.float32)
+        ids = np.zeros((gh, gw), np.int32)
+        self._check(self.L.mvs_engine_depth_normal_map(self.h, view, kind, _ptr(d), _ptr(n), _ptr(ids)))
+        return d, n, ids
+
+    # ---- batched single functions
+    def probe(self, op, recs=None, values=None):
+        if op == PROBE_MATH:
+            x = np.ascontiguousarray(values, dtype=np.float32)
+            out = np.zeros((x.shape[0], 5), np.float32)
+            self._check(self.L.mvs_engine_probe(self.h, op, x.shape[0], None, _ptr(x), None, _ptr(out), None))
+            return out
+        recs = np.ascontiguousarray(recs, dtype=PATCH_DTYPE)
+        n = recs.shape[0]
+        out_rec = np.zeros(n, dtype=PATCH_DTYPE)
+        out_f = np.zeros(n, np.float32)
+        out_i = np.zeros(n, np.int32)
+        self._check(self.L.mvs_engine_probe(self.h, op, n, _ptr(recs), None, _ptr(out_rec), _ptr(out_f), _ptr(out_i)))
+        return out_rec, out_f, out_i

@@ -42,6 +42,7 @@ namespace {
 thread_local std::string g_err;
 
 constexpr int MAXI = ORC_MAX_IMAGES;
+constexpr int LISTCAP = 16; /* engine limit: m_images / m_vimages are truncated to 16 views */
 constexpr int NEWBASE = 0x40000000; /* provisional ids of patches staged by a destination cell */
 
 /* ------------------------------------------------------------------ small vectors */
@@ -623,7 +624,7 @@ void add_images(const Scene& s, Patch& p) {
         if (ic.x < 0.0f || vw.W[s.cfg.level] - 1 <= ic.x || ic.y < 0.0f || vw.H[s.cfg.level] - 1 <= ic.y) continue;
         V4 ray = sub4(vw.center, p.coord);
         ray = div4(ray, norm4(ray));
-        if (s.cosAngle0 <= dot4(ray, p.normal) && p.nimg < MAXI) p.img[p.nimg++] = v;
+        if (s.cosAngle0 <= dot4(ray, p.normal) && p.nimg < LISTCAP) p.img[p.nimg++] = v;
     }
 }
 
@@ -883,7 +884,7 @@ void set_vimages_vgrids(const Scene& s, Patch& p, const DestCtx* ctx) {
         int ix, iy;
         cell_of(s, image, p.coord, ix, iy);
         if (is_visible(s, p, image, ix, iy, s.neighborThreshold, ctx) == 0) continue;
-        if (p.nvimg < MAXI) { p.vimg[p.nvimg] = image; p.vgx[p.nvimg] = ix; p.vgy[p.nvimg] = iy; ++p.nvimg; }
+        if (p.nvimg < LISTCAP) { p.vimg[p.nvimg] = image; p.vgx[p.nvimg] = ix; p.vgy[p.nvimg] = iy; ++p.nvimg; }
     }
 }
 
@@ -1465,7 +1466,7 @@ void from_rec(const orc_patch& r, Patch& p) {
     p.coord = {r.coord[0], r.coord[1], r.coord[2], r.coord[3]};
     p.normal = {r.normal[0], r.normal[1], r.normal[2], r.normal[3]};
     p.ncc = r.ncc; p.dscale = r.dscale; p.ascale = r.ascale; p.tmp = r.tmp;
-    p.nimg = std::min(r.nimages, MAXI); p.nvimg = std::min(r.nvimages, MAXI);
+    p.nimg = std::min(r.nimages, LISTCAP); p.nvimg = std::min(r.nvimages, LISTCAP);
     for (int i = 0; i < p.nimg; ++i) p.img[i] = r.images[i];
     for (int i = 0; i < p.nvimg; ++i) p.vimg[i] = r.vimages[i];
     p.alive = true;
@@ -1500,13 +1501,18 @@ void derive_thresholds(Scene& s) { /* PmMvps::init, pmmvps.cpp:32-36,54-67 */
     s.angleThreshold0 = (float)(60.0f * M_PI / 180.0f);
     s.angleThreshold1 = (float)(60.0f * M_PI / 180.0f);
     s.neighborThreshold = 0.5f; s.neighborThreshold1 = 1.0f; s.neighborThreshold2 = 1.0f;
-    s.cosAngle0 = cosf(s.angleThreshold0);
-    s.cosAngle1 = cosf(s.angleThreshold1);
-    s.cosMinAngle = (float)cos((double)c.maxAngleThreshold); /* angle > minAngle  <=>  dot < cos(minAngle) */
-    s.cosMaxAngle = (float)cos((double)s.angleThreshold1);   /* angle < maxAngle  <=>  dot > cos(maxAngle) */
-    s.cosNeighborTypo = cosf((float)(120.0f / M_PI * 180.0f));
-    s.cosNeighbor120 = (float)cos(120.0f * M_PI / 180.0f);
-    s.sortThreshold = (float)(1.0f - cos(10.0f * M_PI / 180.0f));
+    /* volatile: evaluated by libm at run time, never folded by the compiler */
+    volatile float a0 = s.angleThreshold0, a1 = s.angleThreshold1;
+    volatile double amin = (double)c.maxAngleThreshold, amax = (double)s.angleThreshold1;
+    volatile float typo = (float)(120.0f / M_PI * 180.0f);
+    volatile double d120 = 120.0f * M_PI / 180.0f, d10 = 10.0f * M_PI / 180.0f;
+    s.cosAngle0 = cosf(a0);
+    s.cosAngle1 = cosf(a1);
+    s.cosMinAngle = (float)cos(amin); /* angle > minAngle  <=>  dot < cos(minAngle) */
+    s.cosMaxAngle = (float)cos(amax); /* angle < maxAngle  <=>  dot > cos(maxAngle) */
+    s.cosNeighborTypo = cosf(typo);
+    s.cosNeighbor120 = (float)cos(d120);
+    s.sortThreshold = (float)(1.0f - cos(d10));
     s.ascaleConst = (float)(M_PI / 48.0f);
     s.depth = c.depth;
 }

@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/mvskit_engine.h declares,
+and refuses to run without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mvskit_amd import build, engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_engine()
+    return engine.load_library()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "mvskit_engine.h")).read()
+    declared = set(re.findall(r"\b(mvs_[a-z_]+)\s*\(", hdr))
+    declared -= {"mvs_engine"}  # the opaque struct name
+    assert declared == set(engine.EXPORTS), declared ^ set(engine.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_record_layouts_match_header():
+    assert engine.PATCH_DTYPE.itemsize == 128
+    assert engine.PATCH_DTYPE.fields["images"][1] == 64 and engine.PATCH_DTYPE.fields["vimages"][1] == 96
+    assert C.sizeof(engine.Counters) == 80
+    assert C.sizeof(engine.Config) == 80
+
+
+def test_default_config_follows_option_defaults(lib):
+    c = engine.Config()
+    lib.mvs_default_config(C.byref(c))
+    # Option::Option, pmmvps/option.cpp:19-33
+    assert (c.level, c.csize, c.wsize, c.minImageNum) == (1, 2, 7, 3)
+    assert abs(c.nccThreshold - 0.7) < 1e-7 and abs(c.maxAngleThreshold - np.float32(10 * np.pi / 180)) < 1e-7
+    assert abs(c.quadThreshold - 2.5) < 1e-7 and c.max_propag == 2
+
+
+def test_create_rejects_bad_config_and_missing_gpu(lib):
+    c = engine.Config()
+    lib.mvs_default_config(C.byref(c))
+    h = C.c_void_p()
+    c.nviews = 0
+    assert lib.mvs_engine_create(C.byref(c), C.byref(h)) == -1  # MVS_ERR_ARG
+    c.nviews = 3
+    c.wsize = 9
+    assert lib.mvs_engine_create(C.byref(c), C.byref(h)) == -1
+    if lib.mvs_device_count() == 0:
+        c.wsize = 7
+        assert lib.mvs_engine_create(C.byref(c), C.byref(h)) == -5  # MVS_ERR_NO_DEVICE: no CPU fallback
+        assert b"no HIP device" in lib.mvs_last_error()
+        with pytest.raises(engine.EngineError):
+            engine.Engine(3)

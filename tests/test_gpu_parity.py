@@ -1,0 +1,152 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the CPU oracle on the same inputs.
+
+The oracle runs in TREE64 summation mode (the wavefront butterfly order) so results are expected to be
+bit-identical; every comparison also states the north-star tolerance (1e-3 relative depth, 1e-3 rad normal)."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from mvskit_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-3  # BASELINE.json north_star: depth/normal maps within 1e-3 relative
+
+
+def _pair(scene, **kw):
+    n = scene.nviews
+    okw = dict(level=0, csize=2, wsize=7, minImageNum=kw.pop("minImageNum", 3), schedule=ob.SCHEDULE_ENGINE,
+               sum_mode=ob.SUM_TREE64, enable_check=0, nthreads=8)
+    ekw = dict(level=0, csize=2, wsize=7, minImageNum=okw["minImageNum"], enable_check=0)
+    for k, v in kw.items():
+        okw[k] = v
+        ekw[k] = v
+    o = ob.Oracle(n, **okw)
+    e = engine.Engine(n, **ekw)
+    o.set_scene(scene)
+    e.set_scene(scene)
+    return o, e
+
+
+def test_math_probe_bit_exact(small_plane_scene):
+    o, e = _pair(small_plane_scene, minImageNum=2)
+    x = np.concatenate([np.linspace(-1.5707, 1.5707, 4001), np.linspace(-1, 1, 2001), np.linspace(-30, 30, 1001)]).astype(np.float32)
+    got = e.probe(engine.PROBE_MATH, values=x)
+    L = ob.lib()
+    exp = np.array([[L.orc_sinf(float(v)), L.orc_cosf(float(v)), L.orc_asinf(float(v)), L.orc_acosf(float(v)), L.orc_atanf(float(v))]
+                    for v in x], dtype=np.float32)
+    dom = np.abs(x) <= 1.5708
+    np.testing.assert_array_equal(got[dom, 0], exp[dom, 0])
+    np.testing.assert_array_equal(got[dom, 1], exp[dom, 1])
+    unit = np.abs(x) <= 1.0
+    np.testing.assert_array_equal(got[unit, 2], exp[unit, 2])
+    np.testing.assert_array_equal(got[unit, 3], exp[unit, 3])
+    np.testing.assert_array_equal(got[:, 4], exp[:, 4])
+
+
+def test_pyramid_bit_exact(small_multi_scene):
+    o, e = _pair(small_multi_scene)
+    for v in (0, 3):
+        for level in range(3):
+            np.testing.assert_array_equal(e.pyramid(v, level), o.pyramid(v, level))
+    assert e.grid_dims(1) == o.grid_dims(1)
+
+
+def test_ncc_batch(small_multi_scene):
+    o, e = _pair(small_multi_scene)
+    seeds = synth.make_seeds(small_multi_scene, stride=6)
+    assert seeds.shape[0] > 300
+    _, got, _ = e.probe(engine.PROBE_NCC, seeds)
+    exp = np.array([o.compute_ncc(s) for s in seeds], dtype=np.float32)
+    assert np.isfinite(exp).all()
+    np.testing.assert_allclose(got, exp, rtol=REL_TOL, atol=1e-5)
+    assert (got == exp).mean() > 0.999, f"bit-exact fraction {(got == exp).mean()}"
+
+
+def _cmp_records(a, b, what):
+    assert a["nimages"] == b["nimages"], what
+    n = int(a["nimages"])
+    np.testing.assert_array_equal(a["images"][:n], b["images"][:n], err_msg=what)
+    np.testing.assert_allclose(a["coord"], b["coord"], rtol=REL_TOL, atol=1e-6, err_msg=what)
+    np.testing.assert_allclose(a["normal"], b["normal"], rtol=0, atol=REL_TOL, err_msg=what)
+    for f in ("ncc", "dscale", "ascale"):
+        np.testing.assert_allclose(a[f], b[f], rtol=REL_TOL, atol=1e-6, err_msg=what + f)
+
+
+def test_pre_refine_post_chain(small_multi_scene):
+    o, e = _pair(small_multi_scene)
+    seeds = synth.make_seeds(small_multi_scene, stride=8, seed=31)[:200]
+    pre_rec, _, pre_flag = e.probe(engine.PROBE_PREPROCESS, seeds)
+    keep = []
+    exact = 0
+    for i, s in enumerate(seeds):
+        f, r = o.preprocess(s)
+        assert f == pre_flag[i], i
+        if f == 0:
+            _cmp_records(pre_rec[i], r, f"pre {i}")
+            keep.append(i)
+    assert len(keep) > 50
+    sub = pre_rec[keep]
+    ref_rec, _, _ = e.probe(engine.PROBE_REFINE, sub)
+    _, cost, _ = e.probe(engine.PROBE_COST, sub)
+    post_in = []
+    for j, i in enumerate(keep):
+        x = o.encode(sub[j])
+        assert abs(cost[j] - o.cost(sub[j], x)) <= 1e-6
+        _, r = o.refine(sub[j], (0, 0, j, 0))
+        _cmp_records(ref_rec[j], r, f"refine {j}")
+        exact += int(ref_rec[j]["coord"].tobytes() == r["coord"].tobytes() and ref_rec[j]["normal"].tobytes() == r["normal"].tobytes())
+        post_in.append(r)
+    assert exact >= 0.98 * len(keep), f"refine bit-exact {exact}/{len(keep)}"
+    post_in = np.array(post_in, dtype=ob.PATCH_DTYPE)
+    o.add_patches(seeds)
+    e.upload_patches(seeds)
+    post_rec, _, post_flag = e.probe(engine.PROBE_POSTPROCESS, post_in)
+    npass = 0
+    for j in range(post_in.shape[0]):
+        f, r = o.postprocess(post_in[j])
+        assert f == post_flag[j], j
+        if f == 0:
+            _cmp_records(post_rec[j], r, f"post {j}")
+            assert post_rec[j]["nvimages"] == r["nvimages"]
+            npass += 1
+    assert npass > 20
+
+
+def _maps_close(o, e, nviews):
+    tot = bad = 0
+    for v in range(nviews):
+        for kind in (0, 1):
+            do, no, io = o.depth_normal_map(v, kind)
+            de, ne, ie = e.depth_normal_map(v, kind)
+            assert (np.isnan(do) == np.isnan(de)).all(), f"empty mask differs view {v} kind {kind}"
+            m = ~np.isnan(do)
+            tot += int(m.sum())
+            rel = np.abs(do[m] - de[m]) / np.abs(do[m])
+            ang = np.arccos(np.clip((no[m] * ne[m]).sum(-1), -1, 1))
+            bad += int(((rel > REL_TOL) | (ang > REL_TOL)).sum())
+    return tot, bad
+
+
+def test_propagate_two_iterations_matches_oracle(small_multi_scene):
+    sc = small_multi_scene
+    o, e = _pair(sc, seed=7)
+    seeds = synth.make_seeds(sc, stride=4, seed=5)
+    o.add_patches(seeds)
+    e.upload_patches(seeds)
+    for it in range(2):
+        co = o.propagate(it)
+        ce = e.propagate(it)
+        assert ce["patches"] > 1000
+        for k in ("candidates", "prefiltered", "patches", "fail0", "fail1", "inserted", "replaced", "evals", "view_evals", "trimmed"):
+            assert co[k] == ce[k], (it, k, co, ce)
+        po, pe = o.patches(), e.patches()
+        assert po.shape == pe.shape
+        np.testing.assert_array_equal(po["nimages"], pe["nimages"])
+        np.testing.assert_array_equal(po["images"], pe["images"])
+        np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+        np.testing.assert_allclose(pe["normal"], po["normal"], rtol=0, atol=REL_TOL)
+        np.testing.assert_allclose(pe["ncc"], po["ncc"], rtol=REL_TOL, atol=1e-6)
+        assert (po["coord"].view(np.uint32) == pe["coord"].view(np.uint32)).all(axis=1).mean() > 0.999
+    tot, bad = _maps_close(o, e, sc.nviews)
+    assert tot > 2000 and bad == 0
