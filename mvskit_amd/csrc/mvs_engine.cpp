@@ -192,11 +192,11 @@ int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
     hipStream_t st = e->stream;
     const int64_t nc = e->total_cells;
     DParams p = current_params(e);
-    if (e->ncc_dirty) {
-        HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
-        mvsk_fill_ncc(p, e->misc.p + 1, st);
-        e->ncc_dirty = false;
-    }
+    HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
+    // PatchManager::sortPatches re-scores every patch whose m_ncc < 0 each time it meets it
+    // (patch_manager.cpp:411-415); a wave that finds m_ncc >= 0 exits at once.
+    mvsk_fill_ncc(p, e->misc.p + 1, st);
+    e->ncc_dirty = false;
     const bool vg = want_vgrid(e);
     HIPCHK(hipMemsetAsync(e->cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
     if (vg) HIPCHK(hipMemsetAsync(e->vcnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
@@ -543,6 +543,8 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     HIPCHK(hipEventRecord(e->ev[2], st));
     DCounters hc;
     int32_t herr = 0;
+    unsigned long long fill[2] = {0, 0};  // evaluations spent on seeds whose m_ncc was < 0 (sortPatches)
+    HIPCHK(hipMemcpyAsync(fill, e->misc.p + 1, sizeof fill, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&hc, e->counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&herr, e->error_flag.p, sizeof herr, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -555,7 +557,7 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     if (out) {
         out->candidates = (int64_t)hc.candidates; out->prefiltered = (int64_t)hc.prefiltered; out->patches = (int64_t)hc.patches;
         out->fail0 = (int64_t)hc.fail0; out->fail1 = (int64_t)hc.fail1; out->inserted = (int64_t)hc.inserted; out->replaced = (int64_t)hc.replaced;
-        out->evals = (int64_t)hc.evals; out->view_evals = (int64_t)hc.view_evals; out->trimmed = (int64_t)trimmed;
+        out->evals = (int64_t)(hc.evals + fill[0]); out->view_evals = (int64_t)(hc.view_evals + fill[1]); out->trimmed = (int64_t)trimmed;
     }
     if (herr) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
     return MVS_OK;

@@ -64,6 +64,12 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise EngineError(f"{LIB_PATH} is missing: run `python -m mvskit_amd.build` (the engine has no CPU fallback)")
+    try:
+        # torch bundles its own libamdhip64.so.7; two HIP runtimes in one process cannot both open the GPU.
+        # Loaded first, torch's copy satisfies this library's NEEDED entry (same SONAME), so both share one.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.mvs_last_error.restype = C.c_char_p
