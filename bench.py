@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- patches/s of the propagate+optim iteration on a 12-view 1920x1080 synthetic scene.
+
+One "step" = one Propagate::run(iter) (pmmvps/propagate.cpp:28-64) over all views: two colour passes, each an
+index build + the sweep kernel + the commit, followed by PmMvps::updateThreshold (pmmvps.cpp:70-74).
+`value` = patches (candidates that reached Optim::preProcess, propagate.cpp:182) of all ranks / wall time of
+the K timed steps (max over ranks), inputs resident in HBM.  See DESIGN.md "Measurement".
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_VIEW_EVAL = 588  # 49 samples x 4 texels x 3 B (optim.cpp:835-842 x image.cpp:462-470), SURVEY.md 8d
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--views", type=int, default=12)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--seed-stride", type=int, default=2, help="one seed patch per stride x stride cells per view")
+    ap.add_argument("--refine-steps", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--scene-cache", default=os.path.join("/tmp", "mvskit_scene_cache"))
+    return ap.parse_args()
+
+
+def load_scene(args, rank):
+    """Synthetic cfg2 scene + seeds; cached on local disk so that N ranks do not all render it."""
+    import numpy as np
+
+    from mvskit_amd import synth
+
+    tag = f"v{args.views}_{args.width}x{args.height}_s{args.seed_stride}"
+    path = os.path.join(args.scene_cache, tag + ".npz")
+    if os.path.exists(path):
+        z = np.load(path)
+        sc = synth.Scene(W=args.width, H=args.height, P=z["P"], images=z["images"], centers=z["centers"])
+        return sc, z["seeds"].view(synth.PATCH_DTYPE).reshape(-1)
+    sc = synth.make_scene(nviews=args.views, W=args.width, H=args.height, arc_deg=110.0, radius=4.0, kind="multi")
+    seeds = synth.make_seeds(sc, level=0, csize=2, stride=args.seed_stride, seed=777)
+    sc.points = None
+    sc.normals = None
+    if rank == 0:
+        os.makedirs(args.scene_cache, exist_ok=True)
+        tmp = path + f".tmp{os.getpid()}.npz"
+        np.savez(tmp, P=sc.P, images=sc.images, centers=sc.centers, seeds=seeds.view(np.uint8))
+        os.replace(tmp, path)
+    return sc, seeds
+
+
+def cpu_baseline(args, sc, seeds):
+    """The oracle (oracle/pmmvs_oracle.cpp) in its FAITHFUL schedule -- sequential raster sweep, one thread, the
+    reference's execution model -- on a bounded sample of the same workload: the first source cells of view 0
+    in raster order until about --cpu-seconds have passed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+
+    o = ob.Oracle(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_FAITHFUL, sum_mode=ob.SUM_SEQ,
+                  enable_check=0, refine_steps=args.refine_steps, seed=1)
+    o.set_scene(sc)
+    o.add_patches(seeds)
+    budget, spent, patches, evals = 200, 0.0, 0, 0
+    o.set_cell_budget(budget)
+    t0 = time.perf_counter()
+    c = o.propagate(0)
+    spent = time.perf_counter() - t0
+    patches, evals, cells = c["patches"], c["view_evals"], budget
+    # one more, larger sample sized from the first one
+    if spent < args.cpu_seconds * 0.5 and patches > 0:
+        o2 = ob.Oracle(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_FAITHFUL, sum_mode=ob.SUM_SEQ,
+                       enable_check=0, refine_steps=args.refine_steps, seed=1)
+        o2.set_scene(sc)
+        o2.add_patches(seeds)
+        cells = int(budget * args.cpu_seconds / max(spent, 1e-3))
+        o2.set_cell_budget(cells)
+        t0 = time.perf_counter()
+        c = o2.propagate(0)
+        spent = time.perf_counter() - t0
+        patches, evals = c["patches"], c["view_evals"]
+        o2.close()
+    o.close()
+    return {"value": patches / spent if spent > 0 else 0.0, "unit": "patches/s", "cores": 1, "kind": "port",
+            "sample": f"oracle faithful schedule, single thread, first {cells} source cells of view 0 (iteration 0) of the same scene: "
+                      f"{patches} patches, {evals} view evaluations in {spent:.1f} s",
+            "view_evals_per_s": evals / spent if spent > 0 else 0.0}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from mvskit_amd import engine as eng
+    from mvskit_amd.dist import DeviceExchange
+
+    if rank == 0:
+        sc, seeds = load_scene(args, rank)
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        sc, seeds = load_scene(args, rank)
+
+    e = eng.Engine(args.views, level=0, csize=2, wsize=7, minImageNum=3, enable_check=0, seed=1, refine_steps=args.refine_steps,
+                   view_begin=rank, view_stride=world, device=local_rank)
+    e.set_scene(sc)
+    e.upload_patches(seeds)
+    ex = DeviceExchange(device) if world > 1 else None
+
+    def step(it):
+        c = ex.propagate(e, it) if ex else e.propagate(it)
+        t = e.timing()
+        e.update_threshold()
+        return c, t
+
+    it = 0
+    for _ in range(args.warmup):
+        step(it)
+        it += 1
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    patches = view_evals = evals = 0
+    sweep_ms = index_ms = commit_ms = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        c, t = step(it)
+        it += 1
+        patches += c["patches"]; view_evals += c["view_evals"]; evals += c["evals"]
+        if ex is None:
+            sweep_ms += t["sweep_ms"]; index_ms += t["index_ms"]; commit_ms += t["commit_ms"]; launches += t["sweep_launches"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt, float(patches), float(view_evals)], dtype=torch.float64, device=device)
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx[0]); patches = int(sm[1]); view_evals = int(sm[2])
+    n_alive = e.num_patches()
+
+    if rank == 0:
+        out = {
+            "metric": "patches/s (propagate+optim iteration), 12-view 1080p",
+            "value": patches / dt,
+            "unit": "patches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.views}-view {args.width}x{args.height} synthetic scene (3 planes + sphere), level 0, csize 2, wsize 7, "
+                                   f"minImageNum 3, 1 seed per {args.seed_stride}x{args.seed_stride} cells per view, {args.steps} iterations after {args.warmup} warm-up",
+                       "views": args.views, "width": args.width, "height": args.height, "csize": 2, "wsize": 7,
+                       "refine_evals": 1 + 3 * args.refine_steps, "check_depth2": False,
+                       "parallelism": "single GPU" if world == 1 else f"views sharded over {world} GPUs, RCCL all-gather of patch records per colour pass"},
+            "patches": patches,
+            "view_evals": view_evals,
+            "pool_alive": n_alive,
+        }
+        if ex is None and sweep_ms > 0:
+            alg = view_evals * ALG_BYTES_PER_VIEW_EVAL
+            ach = alg / (sweep_ms * 1e-3) / 1e9
+            traffic = None
+            prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(prof):
+                try:
+                    traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "k_sweep", "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
+                               "algorithmic_bytes_per_launch": alg / max(launches, 1),
+                               "index_ms": index_ms, "commit_ms": commit_ms, "sweep_ms": sweep_ms}
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args, sc, seeds)
+        print(json.dumps(out))
+    e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""View-sharded Propagate::run across the GPUs of one node.
+
+Every rank holds the whole patch pool and all image pyramids (98 MB for 12 x 1080p), sweeps the views
+`rank, rank + world, ...` (mvs_config.view_begin / view_stride) and, after each colour pass, exchanges what
+it created: the new patch records (128 B each, ordered (view, cell, sequence)) and the ids of the patches
+it evicted.  One all-gather of counts, one padded all-gather of records, one of kill ids -- over RCCL/xGMI
+when the tensors live on the GPU, over gloo in the CPU tests.  Every rank then commits the union in view
+order, so all pools stay identical and the result does not depend on the number of ranks.
+
+The `engine` argument only needs the pass / export / commit methods; tests drive this module with an
+oracle-backed stand-in on CPU, bench.py with mvskit_amd.engine.Engine on GPUs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RECORD_BYTES = 128
+
+
+def owner_of(view: int, world: int) -> int:
+    return view % world
+
+
+def merge_in_view_order(per_rank_records, per_rank_view_counts, nviews, world):
+    """Concatenate each rank's export (its own views in ascending order) into global view order.
+    per_rank_records[r]: uint8 array/tensor [n_r, 128]; per_rank_view_counts[r]: int array [nviews]."""
+    offsets = [0] * world
+    parts = []
+    for v in range(nviews):
+        r = owner_of(v, world)
+        c = int(per_rank_view_counts[r][v])
+        if c:
+            parts.append(per_rank_records[r][offsets[r]: offsets[r] + c])
+            offsets[r] += c
+    return parts
+
+
+class HostExchange:
+    """Exchange through host numpy buffers + torch.distributed (gloo).  Used by the CPU tests."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def exchange(self, new_recs: np.ndarray, per_view: np.ndarray, kills: np.ndarray, nviews: int):
+        import torch
+
+        dist, world = self.dist, self.world
+        counts = torch.zeros(world, nviews + 2, dtype=torch.int64)
+        mine = torch.zeros(nviews + 2, dtype=torch.int64)
+        mine[:nviews] = torch.as_tensor(per_view.astype(np.int64))
+        mine[nviews] = new_recs.shape[0]
+        mine[nviews + 1] = kills.shape[0]
+        lst = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(lst, mine, group=self.group)
+        counts = torch.stack(lst)
+        max_new, max_kill = int(counts[:, nviews].max()), int(counts[:, nviews + 1].max())
+        rec_bytes = np.zeros((max(max_new, 1), RECORD_BYTES), dtype=np.uint8)
+        if new_recs.shape[0]:
+            rec_bytes[: new_recs.shape[0]] = new_recs.view(np.uint8).reshape(-1, RECORD_BYTES)
+        g = [torch.zeros(rec_bytes.shape, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(g, torch.from_numpy(rec_bytes), group=self.group)
+        kpad = np.full(max(max_kill, 1), -1, dtype=np.int32)
+        kpad[: kills.shape[0]] = kills
+        gk = [torch.zeros(kpad.shape, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(gk, torch.from_numpy(kpad), group=self.group)
+        parts = merge_in_view_order([t.numpy() for t in g], [counts[r, :nviews].numpy() for r in range(world)], nviews, world)
+        allrec = np.concatenate(parts) if parts else np.zeros((0, RECORD_BYTES), np.uint8)
+        allkill = np.concatenate([gk[r].numpy()[: int(counts[r, nviews + 1])] for r in range(world)]) if max_kill else np.zeros(0, np.int32)
+        return allrec, allkill
+
+
+def sharded_propagate_host(engine, iter_index: int, exchange: HostExchange, nviews: int, patch_dtype):
+    """Propagate::run(iter) with host-side exchange; `engine` exposes engine_pass / export_new / export_kills / commit."""
+    totals = None
+    for p in range(2):
+        c = engine.engine_pass(iter_index, p)
+        new, per_view = engine.export_new()
+        kills = engine.export_kills()
+        allrec, allkill = exchange.exchange(new, per_view, kills, nviews)
+        engine.commit(allrec.view(patch_dtype).reshape(-1), allkill)
+        totals = c if totals is None else {k: totals[k] + c[k] for k in c}
+    return totals
+
+
+class DeviceExchange:
+    """Exchange through device tensors + torch.distributed backend "nccl" (= RCCL over xGMI on ROCm)."""
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.device = device
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def propagate(self, engine, iter_index: int):
+        """One Propagate::run(iter) on the rank's views; returns this rank's counters."""
+        torch, dist, world = self.torch, self.dist, self.world
+        nviews = engine.cfg.nviews
+        totals = None
+        for p in range(2):
+            c = engine.engine_pass(iter_index, p)
+            n_new, n_kill, per_view = engine.export_counts()
+            mine = torch.zeros(nviews + 2, dtype=torch.int64, device=self.device)
+            mine[:nviews] = torch.as_tensor(per_view.astype(np.int64), device=self.device)
+            mine[nviews], mine[nviews + 1] = n_new, n_kill
+            counts = torch.zeros(world, nviews + 2, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(counts, mine, group=self.group)
+            counts_h = counts.cpu().numpy()
+            max_new, max_kill = int(counts_h[:, nviews].max()), int(counts_h[:, nviews + 1].max())
+            rec = torch.zeros(max(max_new, 1), RECORD_BYTES, dtype=torch.uint8, device=self.device)
+            kil = torch.full((max(max_kill, 1),), -1, dtype=torch.int32, device=self.device)
+            torch.cuda.synchronize(self.device)  # rec/kil were filled on torch's stream; the engine writes on its own
+            engine.export_device(rec.data_ptr(), rec.shape[0], kil.data_ptr(), kil.shape[0])
+            grec = torch.empty(world, rec.shape[0], RECORD_BYTES, dtype=torch.uint8, device=self.device)
+            gkil = torch.empty(world, kil.shape[0], dtype=torch.int32, device=self.device)
+            dist.all_gather_into_tensor(grec, rec, group=self.group)
+            dist.all_gather_into_tensor(gkil, kil, group=self.group)
+            parts = merge_in_view_order([grec[r] for r in range(world)], [counts_h[r, :nviews] for r in range(world)], nviews, world)
+            allrec = torch.cat(parts) if parts else torch.zeros(0, RECORD_BYTES, dtype=torch.uint8, device=self.device)
+            allkill = torch.cat([gkil[r, : int(counts_h[r, nviews + 1])] for r in range(world)]) if max_kill else torch.zeros(0, dtype=torch.int32, device=self.device)
+            allrec, allkill = allrec.contiguous(), allkill.contiguous()
+            torch.cuda.synchronize(self.device)  # the engine commits on its own HIP stream
+            engine.commit_device(allrec.data_ptr(), allrec.shape[0], allkill.data_ptr(), allkill.shape[0])
+            totals = c if totals is None else {k: totals[k] + c[k] for k in c}
+        return totals
