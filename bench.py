@@ -24,6 +24,10 @@ ALG_BYTES_PER_VIEW_EVAL = 588  # 49 samples x 4 texels x 3 B (optim.cpp:835-842 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,28 +78,14 @@ def cpu_baseline(args, sc, seeds):
                   enable_check=0, refine_steps=args.refine_steps, seed=1)
     o.set_scene(sc)
     o.add_patches(seeds)
-    budget, spent, patches, evals = 200, 0.0, 0, 0
-    o.set_cell_budget(budget)
+    o.set_time_budget(args.cpu_seconds)
     t0 = time.perf_counter()
     c = o.propagate(0)
     spent = time.perf_counter() - t0
-    patches, evals, cells = c["patches"], c["view_evals"], budget
-    # one more, larger sample sized from the first one
-    if spent < args.cpu_seconds * 0.5 and patches > 0:
-        o2 = ob.Oracle(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_FAITHFUL, sum_mode=ob.SUM_SEQ,
-                       enable_check=0, refine_steps=args.refine_steps, seed=1)
-        o2.set_scene(sc)
-        o2.add_patches(seeds)
-        cells = int(budget * args.cpu_seconds / max(spent, 1e-3))
-        o2.set_cell_budget(cells)
-        t0 = time.perf_counter()
-        c = o2.propagate(0)
-        spent = time.perf_counter() - t0
-        patches, evals = c["patches"], c["view_evals"]
-        o2.close()
+    patches, evals = c["patches"], c["view_evals"]
     o.close()
     return {"value": patches / spent if spent > 0 else 0.0, "unit": "patches/s", "cores": 1, "kind": "port",
-            "sample": f"oracle faithful schedule, single thread, first {cells} source cells of view 0 (iteration 0) of the same scene: "
+            "sample": f"oracle faithful schedule, single thread, the source cells of view 0 in raster order (iteration 0) of the same scene until {args.cpu_seconds:.0f} s had passed: "
                       f"{patches} patches, {evals} view evaluations in {spent:.1f} s",
             "view_evals_per_s": evals / spent if spent > 0 else 0.0}
 
@@ -134,14 +124,20 @@ def main():
 
     e = eng.Engine(args.views, level=0, csize=2, wsize=7, minImageNum=3, enable_check=0, seed=1, refine_steps=args.refine_steps,
                    view_begin=rank, view_stride=world, device=local_rank)
+    if rank == 0:
+        log(f"scene ready: {sc.nviews} views {sc.W}x{sc.H}, {seeds.shape[0]} seeds")
     e.set_scene(sc)
     e.upload_patches(seeds)
     ex = DeviceExchange(device) if world > 1 else None
 
     def step(it):
+        ts = time.perf_counter()
         c = ex.propagate(e, it) if ex else e.propagate(it)
         t = e.timing()
         e.update_threshold()
+        if rank == 0:
+            log(f"iter {it}: {time.perf_counter() - ts:.3f} s, patches {c['patches']}, candidates {c['candidates']}, view_evals {c['view_evals']}, "
+                f"inserted {c['inserted']}, replaced {c['replaced']}, timing {t}")
         return c, t
 
     it = 0
@@ -212,6 +208,7 @@ def main():
                                "algorithmic_bytes_per_launch": alg / max(launches, 1),
                                "index_ms": index_ms, "commit_ms": commit_ms, "sweep_ms": sweep_ms}
         if world == 1 and args.cpu_seconds > 0:
+            log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(args, sc, seeds)
         print(json.dumps(out))
     e.close()

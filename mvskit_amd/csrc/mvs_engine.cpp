@@ -57,7 +57,7 @@ struct mvs_engine {
     std::vector<uint8_t*> mask_bufs;
     int total_cells = 0;
     // pool
-    DevBuf<DPatch> pool;
+    DevBuf<DPatch> pool, pool_alt;  // pool_alt: target of the stable compaction done at every commit
     DevBuf<uint8_t> kill;
     int64_t pool_n = 0;
     bool ncc_dirty = false;
@@ -256,6 +256,24 @@ int ensure_counts(mvs_engine* e) {  // commit_count + scans for the staged pass
     return MVS_OK;
 }
 
+// Stable compaction of the pool: dead records (evicted, trimmed) are dropped, the relative order of the
+// survivors -- the only thing ids are used for -- is kept.  Runs at every commit, on every rank alike.
+int compact_pool(mvs_engine* e) {
+    hipStream_t st = e->stream;
+    if (e->pool_n == 0) return MVS_OK;
+    mvsk_alive_count(e->pool.p, e->pool_n, e->kill_cnt.p, st);
+    mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, e->scan_tmp.p, st);
+    int32_t alive = 0;
+    HIPCHK(hipMemcpyAsync(&alive, e->kill_base.p + e->pool_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (alive == e->pool_n) return MVS_OK;
+    mvsk_alive_gather(e->pool.p, e->pool_n, e->kill_base.p, e->pool_alt.p, e->pool_alt.cap, st);
+    std::swap(e->pool.p, e->pool_alt.p);
+    std::swap(e->pool.cap, e->pool_alt.cap);
+    e->pool_n = alive;
+    return MVS_OK;
+}
+
 void add_counters(mvs_counters& a, const mvs_counters& b) {
     a.candidates += b.candidates; a.prefiltered += b.prefiltered; a.patches += b.patches; a.fail0 += b.fail0; a.fail1 += b.fail1;
     a.inserted += b.inserted; a.replaced += b.replaced; a.evals += b.evals; a.view_evals += b.view_evals; a.trimmed += b.trimmed;
@@ -311,7 +329,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     (void)hipStreamSynchronize(e->stream);
     free_views(e);
-    e->dviews.release(); e->pool.release(); e->kill.release();
+    e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
     e->vcursor.release(); e->vids.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
@@ -381,8 +399,8 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
     if (e->cnt.ensure(nc + 2) || e->start.ensure(nc + 2) || e->cursor.ensure(nc + 2) || e->vcnt.ensure(nc + 2) || e->vstart.ensure(nc + 2) ||
         e->vcursor.ensure(nc + 2) || e->dpgrid.ensure(nc + 2) || e->best.ensure(nc + 2))
         return MVS_ERR_HIP;
-    const int64_t pool_cap = e->cfg.max_patches > 0 ? e->cfg.max_patches : 4 * nc;
-    if (e->pool.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;
+    const int64_t pool_cap = e->cfg.max_patches > 0 ? e->cfg.max_patches : 6 * nc;
+    if (e->pool.ensure(pool_cap) || e->pool_alt.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;
     HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)pool_cap, st));
     // jobs of one colour pass over every view (upper bound, used to size the staging bookkeeping)
     int64_t njobs_max = 0;
@@ -394,6 +412,7 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
     const int64_t scan_n = std::max<int64_t>(std::max<int64_t>(nc, pool_cap), njobs_max);
     if (e->scan_tmp.ensure(scan_n / 256 + 4096)) return MVS_ERR_HIP;
     if (e->staging.ensure(std::max<int64_t>(pool_cap / 2, 1024))) return MVS_ERR_HIP;
+    if (e->tmp_rec_out.ensure(16)) return MVS_ERR_HIP;
     HIPCHK(hipStreamSynchronize(st));
     e->pool_n = 0;
     e->have_views = true;
@@ -593,11 +612,12 @@ int mvs_engine_commit_device(mvs_engine* e, const void* d_new, int64_t n_new, co
     mvsk_apply_kill_ids(e->pool.p, (const int32_t*)d_kill, n_kill, e->pool_n, st);
     mvsk_append_records(e->pool.p, e->pool_n, (const DPatch*)d_new, n_new, st);
     if (e->pool_n > 0) HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));
+    e->pool_n += n_new;
+    if (int r = compact_pool(e)) return r;
     HIPCHK(hipEventRecord(e->ev[3], st));
     HIPCHK(hipStreamSynchronize(st));
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->timing.commit_ms = ms;
-    e->pool_n += n_new;
     e->staged = false; e->counted = false; e->index_valid = false;
     return MVS_OK;
 }
@@ -611,11 +631,12 @@ int mvs_engine_commit_local(mvs_engine* e) {
     if (e->pool_n + e->n_new > e->pool.cap) { g_err = "mvs_engine_commit_local: patch pool capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
     if (e->n_new > 0) mvsk_commit_copy(e->sa, e->job_base_scan.p, e->pool.p + e->pool_n, e->pool.cap - e->pool_n, nullptr, 0, st);
     mvsk_apply_kill_flags(e->pool.p, e->kill.p, e->pool_n, st);
+    e->pool_n += e->n_new;
+    if (int r = compact_pool(e)) return r;
     HIPCHK(hipEventRecord(e->ev[3], st));
     HIPCHK(hipStreamSynchronize(st));
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->timing.commit_ms = ms;
-    e->pool_n += e->n_new;
     e->staged = false; e->counted = false; e->index_valid = false;
     return MVS_OK;
 }

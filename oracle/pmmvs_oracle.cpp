@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -213,6 +214,7 @@ struct Scene {
     std::vector<std::vector<int>> csr_start, csr_ids, vcsr_start, vcsr_ids;
     std::vector<DestCtx> staged_cells; /* results of the last engine pass, order (view, cell) */
     int64_t cell_budget = 0;
+    double time_budget = 0.0; /* faithful schedule: stop the sweep after this many seconds (0 = off) */
     bool finalized = false;
     orc_counters cnt{};
 };
@@ -1227,6 +1229,7 @@ void propagate_patch_faithful(Scene& s, int src, int image, int index) {
  * row-wrapping targets skipped; D3: the `end` cell is never a source, kept) */
 void propagate_faithful(Scene& s, int iter) {
     int64_t visited = 0;
+    const auto t_start = std::chrono::steady_clock::now();
     for (int image = 0; image < s.cfg.nviews; ++image) {
         const int gw = s.views[image].gw, gh = s.views[image].gh;
         int start = 0, end = gw * gh - 1, inc = 1;
@@ -1237,6 +1240,8 @@ void propagate_faithful(Scene& s, int iter) {
             int np = (int)l.size();
             if (np == 0) continue;
             if (s.cell_budget > 0 && visited >= s.cell_budget) return;
+            if (s.time_budget > 0.0 && (visited & 15) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > s.time_budget) return;
             ++visited;
             if (np > s.cap) {
                 for (int i = np - 1; i >= s.cap; --i) { remove_patch_live(s, l[i]); s.cnt.trimmed++; }
@@ -1644,6 +1649,7 @@ int orc_clear_patches(orc_scene* h) {
     return 0;
 }
 int orc_set_cell_budget(orc_scene* h, int64_t n) { h->s.cell_budget = n; return 0; }
+int orc_set_time_budget(orc_scene* h, double seconds) { h->s.time_budget = seconds; return 0; }
 
 int orc_engine_pass(orc_scene* h, int iter, int pass, orc_counters* out) {
     Scene& s = h->s;

@@ -107,6 +107,7 @@ int orc_clear_patches(orc_scene* s);
 int orc_propagate(orc_scene* s, int iter, orc_counters* out);  /* Propagate::run(iter) */
 /* faithful schedule only: bound the work (for timing a sample). <=0 means unlimited. */
 int orc_set_cell_budget(orc_scene* s, int64_t max_source_cells);
+int orc_set_time_budget(orc_scene* s, double seconds);
 
 /* view-sharded exchange (engine schedule): records created by the last pass / ids killed */
 int orc_engine_pass(orc_scene* s, int iter, int pass, orc_counters* out); /* sweep without commit */

@@ -77,6 +77,7 @@ def lib():
     L.orc_clear_patches.argtypes = [vp]
     L.orc_propagate.argtypes = [vp, C.c_int, C.POINTER(Counters)]
     L.orc_set_cell_budget.argtypes = [vp, C.c_int64]
+    L.orc_set_time_budget.argtypes = [vp, C.c_double]
     L.orc_engine_pass.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Counters)]
     L.orc_export_new.argtypes = [vp, C.c_int, vp, vp]
     L.orc_export_kills.argtypes = [vp, C.c_int, vp]
@@ -225,6 +226,9 @@ class Oracle:
 
     def set_cell_budget(self, n):
         self.L.orc_set_cell_budget(self.h, n)
+
+    def set_time_budget(self, seconds):
+        self.L.orc_set_time_budget(self.h, float(seconds))
 
     def engine_pass(self, it, p):
         c = Counters()
