@@ -42,5 +42,24 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB_PATH = os.path.join(LIB_DIR, "libmvskit_host.so")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """The host-side mirror of the reference classes (C++, g++), linked against the engine's C ABI."""
+    src = os.path.join(HOST_DIR, "pmmvps_host.cpp")
+    deps = [src, os.path.join(HOST_DIR, "pmmvps_host.hpp"), os.path.join(ROOT, "include", "mvskit_engine.h"), LIB_PATH]
+    if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
+        return HOST_LIB_PATH
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", HOST_LIB_PATH,
+           "-L", LIB_DIR, "-lmvskit_engine", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_engine(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

@@ -1,0 +1,441 @@
+// pmmvps_host.cpp -- see pmmvps_host.hpp.  Host code around the C ABI; nothing here computes the hot path.
+#include "pmmvps_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace mvshost {
+
+using std::cerr;
+using std::endl;
+using std::ifstream;
+using std::ofstream;
+
+// ------------------------------------------------------------------ Option (pmmvps/option.cpp)
+Option::Option() {  // option.cpp:19-33
+    m_nimages = 0; m_nillums = 1;
+    m_level = 1; m_csize = 2; m_wsize = 7; m_nccThreshold = 0.7f; m_minImageNum = 3; m_cpu = 4;
+    m_setEdge = 0; m_useBound = 0; m_useVisData = 0; m_sequence = -1; m_flag = -10;
+    m_maxAngleThreshold = (float)(10.0f * M_PI / 180.0f);
+    m_quadThreshold = 2.5f;
+}
+
+int Option::init(const string prefix, const string option) {  // option.cpp:35-149
+    m_prefix = prefix; m_option = option;
+    ifstream ifstr((prefix + option).c_str());
+    if (!ifstr.is_open()) { cerr << "Cannot open option file: " << prefix + option << endl; return -1; }
+    string name;
+    while (ifstr >> name) {
+        if (name[0] == '#') { string rest; std::getline(ifstr, rest); continue; }
+        if (name == "image") ifstr >> m_nimages;
+        else if (name == "illum") ifstr >> m_nillums;
+        else if (name == "level") ifstr >> m_level;
+        else if (name == "csize") ifstr >> m_csize;
+        else if (name == "threshold") ifstr >> m_nccThreshold;
+        else if (name == "wsize") ifstr >> m_wsize;
+        else if (name == "minImageNum") ifstr >> m_minImageNum;
+        else if (name == "CPU") ifstr >> m_cpu;
+        else if (name == "setEdge") ifstr >> m_setEdge;
+        else if (name == "useBound") ifstr >> m_useBound;
+        else if (name == "useVisData") ifstr >> m_useVisData;
+        else if (name == "sequence") ifstr >> m_sequence;
+        else if (name == "maxAngle") { ifstr >> m_maxAngleThreshold; m_maxAngleThreshold *= (float)(M_PI / 180.0f); }
+        else if (name == "quad") ifstr >> m_quadThreshold;
+        else if (name == "images") {
+            ifstr >> m_flag;
+            if (m_flag == -1) {
+                int first, last;
+                ifstr >> first >> last;
+                for (int i = first; i < last; ++i) m_images.push_back(i);
+            } else if (0 < m_flag) {
+                for (int i = 0; i < m_flag; ++i) { int idx; ifstr >> idx; m_images.push_back(idx); }
+            } else { cerr << "flag is not valid: " << m_flag << endl; return -1; }
+        } else { cerr << "Unrecognizable option: " << name << endl; return -1; }
+    }
+    if (m_flag == -10) { cerr << "m_flag not specified: " << m_flag << endl; return -1; }
+    if (m_nimages == 0) m_nimages = (int)m_images.size();
+    for (int i = 0; i < (int)m_images.size(); ++i) m_dict[m_images[i]] = i;
+    initVisdata();
+    return 0;
+}
+
+void Option::initVisdata() {  // option.cpp:151-170
+    if (m_useVisData != 0) return;
+    const int n = (int)m_images.size();
+    m_visdata2.assign(n, {});
+    for (int y = 0; y < n; ++y) for (int x = 0; x < n; ++x) if (x != y) m_visdata2[y].push_back(x);
+}
+
+// ------------------------------------------------------------------ Photo / PhotoSet
+int Photo::initCamera(const string cname) {  // camera.cpp:27-63
+    ifstream ifstr(cname.c_str());
+    string header;
+    if (!(ifstr >> header)) { cerr << "Cannot read camera file " << cname << endl; return -1; }
+    if (header == "CONTOUR") m_txtType = 0;
+    else if (header == "CONTOUR2") m_txtType = 2;
+    else { cerr << "Unrecognizable text format" << endl; return -1; }
+    float p[12];
+    for (int i = 0; i < 12; ++i) if (!(ifstr >> p[i])) { cerr << "Short camera file " << cname << endl; return -1; }
+    if (m_txtType == 0) {  // camera.cpp:110-116
+        for (int i = 0; i < 12; ++i) m_projection[i] = p[i];
+        return 0;
+    }
+    // CONTOUR2: K from (fx, fy, skew, cx, cy, -), Rt from Euler degrees + t (camera.cpp:117-134, quat2proj 241-261)
+    const float a = (float)(p[6] * M_PI / 180.0), b = (float)(p[7] * M_PI / 180.0), g = (float)(p[8] * M_PI / 180.0);
+    const float s1 = sinf(a), s2 = sinf(b), s3 = sinf(g), c1 = cosf(a), c2 = cosf(b), c3 = cosf(g);
+    const float Rt[3][4] = {{c2 * c3, c3 * s2 * s1 - s3 * c1, c3 * s2 * c1 + s3 * s1, p[9]},
+                            {s3 * c2, s3 * s2 * s1 + c3 * c1, s3 * s2 * c1 - c3 * s1, p[10]},
+                            {-s2, c2 * s1, c2 * c1, p[11]}};
+    const float K[3][3] = {{p[0], p[2], p[3]}, {0.0f, p[1], p[4]}, {0.0f, 0.0f, 1.0f}};
+    for (int y = 0; y < 3; ++y) for (int x = 0; x < 4; ++x) {
+        float s = 0.0f;
+        for (int k = 0; k < 3; ++k) s += K[y][k] * Rt[k][x];
+        m_projection[4 * y + x] = s;
+    }
+    return 0;
+}
+
+static bool pnm_header(std::istream& is, const char* magic, int& w, int& h, int& maxv) {
+    string m;
+    is >> m;
+    if (m != magic) return false;
+    auto skip = [&]() { while (is >> std::ws && is.peek() == '#') { string l; std::getline(is, l); } };
+    skip(); is >> w; skip(); is >> h; skip(); is >> maxv;
+    is.get();
+    return (bool)is && w > 0 && h > 0 && maxv == 255;
+}
+int Photo::readPpm(const string iname) {
+    ifstream is(iname.c_str(), std::ios::binary);
+    int w, h, maxv;
+    if (!is.is_open() || !pnm_header(is, "P6", w, h, maxv)) return -1;
+    m_width = w; m_height = h;
+    m_image.resize((size_t)w * h * 3);
+    is.read((char*)m_image.data(), (std::streamsize)m_image.size());
+    return is ? 0 : -1;
+}
+int Photo::readPgmMask(const string mname) {
+    ifstream is(mname.c_str(), std::ios::binary);
+    int w, h, maxv;
+    if (!is.is_open() || !pnm_header(is, "P5", w, h, maxv) || w != m_width || h != m_height) return -1;
+    m_mask.resize((size_t)w * h);
+    is.read((char*)m_mask.data(), (std::streamsize)m_mask.size());
+    for (auto& m : m_mask) m = m > 127 ? 255 : 0;
+    return is ? 0 : -1;
+}
+
+int PhotoSet::init(const vector<int>& images, const string prefix, const int nimages, const int nillums, const int, const int, const int) {
+    m_images = images; m_nimages = nimages; m_nillums = nillums; m_prefix = prefix;  // photoSet.cpp:20-61
+    for (int i = 0; i < m_nimages; ++i) m_dict[images[i]] = i;
+    m_photos.assign(m_nimages, Photo());
+    for (int i = 0; i < m_nimages; ++i) {
+        char iname[1024], cname[1024], mname[1024];
+        snprintf(iname, sizeof iname, "%simage/%04d%04d.ppm", prefix.c_str(), i, 0);
+        snprintf(mname, sizeof mname, "%smask/%08d.pgm", prefix.c_str(), i);
+        snprintf(cname, sizeof cname, "%stxt/%08d.txt", prefix.c_str(), i);
+        if (m_photos[i].initCamera(cname) != 0) return -1;
+        if (m_photos[i].readPpm(iname) != 0) { cerr << "Unsupported image format found (only binary PPM): " << iname << endl; return -1; }
+        (void)m_photos[i].readPgmMask(mname);
+    }
+    return 0;
+}
+void PhotoSet::setPhoto(int index, int width, int height, const float P[12], const unsigned char* rgb, const unsigned char* mask) {
+    if ((int)m_photos.size() <= index) m_photos.resize(index + 1);
+    Photo& ph = m_photos[index];
+    ph.m_width = width; ph.m_height = height;
+    memcpy(ph.m_projection, P, sizeof ph.m_projection);
+    ph.m_image.assign(rgb, rgb + (size_t)width * height * 3);
+    if (mask) ph.m_mask.assign(mask, mask + (size_t)width * height); else ph.m_mask.clear();
+    m_nimages = (int)m_photos.size();
+}
+int PhotoSet::image2index(const int image) const {  // photoSet.cpp:251-259
+    auto pos = m_dict.find(image);
+    return pos == m_dict.end() ? -1 : pos->second;
+}
+
+// ------------------------------------------------------------------ Patch (pmmvps/patch.cpp)
+Patch::Patch() {
+    m_coord = {0, 0, 0, 1}; m_normal = {0, 0, 0, 0};
+    m_ncc = -1.0f; m_nimages = 0; m_iter = 0; m_collected = 0; m_flag = 0; m_dflag = 0; m_fix = 0; m_id = -1;
+    m_dscale = 0.0f; m_ascale = 0.0f; m_tmp = 0.0f;
+}
+float Patch::score2(const float threshold) const { return std::max(0.0f, m_ncc - threshold) * (int)m_images.size(); }
+
+std::istream& operator>>(std::istream& istr, Patch& rhs) {
+    string header;
+    int itmp = 0;
+    istr >> header;
+    for (int k = 0; k < 4; ++k) istr >> rhs.m_coord[k];
+    for (int k = 0; k < 4; ++k) istr >> rhs.m_normal[k];
+    istr >> rhs.m_ncc >> rhs.m_dscale >> rhs.m_ascale;
+    if (header == "PATCHA") { int type; float dir[4]; istr >> type >> dir[0] >> dir[1] >> dir[2] >> dir[3]; }
+    istr >> itmp;
+    rhs.m_images.resize(std::max(itmp, 0));
+    for (int i = 0; i < itmp; ++i) istr >> rhs.m_images[i];
+    istr >> itmp;
+    rhs.m_vimages.resize(std::max(itmp, 0));
+    for (int i = 0; i < itmp; ++i) istr >> rhs.m_vimages[i];
+    return istr;
+}
+std::ostream& operator<<(std::ostream& ostr, const Patch& rhs) {
+    ostr << "PATCHES" << endl
+         << rhs.m_coord[0] << " " << rhs.m_coord[1] << " " << rhs.m_coord[2] << " " << rhs.m_coord[3] << endl
+         << rhs.m_normal[0] << " " << rhs.m_normal[1] << " " << rhs.m_normal[2] << " " << rhs.m_normal[3] << endl
+         << rhs.m_ncc << ' ' << rhs.m_dscale << ' ' << rhs.m_ascale << endl
+         << (int)rhs.m_images.size() << endl;
+    for (int v : rhs.m_images) ostr << v << ' ';
+    ostr << endl << (int)rhs.m_vimages.size() << endl;
+    for (int v : rhs.m_vimages) ostr << v << ' ';
+    ostr << endl;
+    return ostr;
+}
+
+static mvs_patch to_record(const Patch& p) {
+    mvs_patch r;
+    memset(&r, 0, sizeof r);
+    for (int k = 0; k < 4; ++k) { r.coord[k] = p.m_coord[k]; r.normal[k] = p.m_normal[k]; }
+    r.ncc = p.m_ncc; r.dscale = p.m_dscale; r.ascale = p.m_ascale; r.tmp = p.m_tmp;
+    r.nimages = std::min<int>((int)p.m_images.size(), MVS_LIST_CAP);
+    r.nvimages = std::min<int>((int)p.m_vimages.size(), MVS_LIST_CAP);
+    for (int i = 0; i < r.nimages; ++i) r.images[i] = (uint8_t)p.m_images[i];
+    for (int i = 0; i < r.nvimages; ++i) r.vimages[i] = (uint8_t)p.m_vimages[i];
+    r.flags = 1;
+    return r;
+}
+static Ppatch from_record(const mvs_patch& r) {
+    Ppatch pp(new Patch());
+    for (int k = 0; k < 4; ++k) { pp->m_coord[k] = r.coord[k]; pp->m_normal[k] = r.normal[k]; }
+    pp->m_ncc = r.ncc; pp->m_dscale = r.dscale; pp->m_ascale = r.ascale; pp->m_tmp = r.tmp;
+    pp->m_images.assign(r.images, r.images + r.nimages);
+    pp->m_vimages.assign(r.vimages, r.vimages + r.nvimages);
+    pp->m_nimages = r.nimages; pp->m_id = r.id;
+    return pp;
+}
+
+// ------------------------------------------------------------------ PatchManager
+void PatchManager::init() {  // patch_manager.cpp:24-51 (the grids themselves are device-side)
+    m_gwidths.assign(m_pmmvps.m_nimages, 0);
+    m_gheights.assign(m_pmmvps.m_nimages, 0);
+    for (int i = 0; i < m_pmmvps.m_nimages; ++i) mvs_engine_grid_dims(m_pmmvps.m_engine, i, &m_gwidths[i], &m_gheights[i]);
+}
+void PatchManager::image2index(Patch& patch) {  // patch_manager.cpp:53-63
+    vector<int> out;
+    for (int im : patch.m_images) { const int idx = m_pmmvps.m_photoSet.image2index(im); if (idx != -1) out.push_back(idx); }
+    patch.m_images.swap(out);
+}
+void PatchManager::index2image(Patch& patch) {  // patch_manager.cpp:65-73
+    for (int& v : patch.m_images) v = m_pmmvps.m_photoSet.m_images[v];
+    for (int& v : patch.m_vimages) v = m_pmmvps.m_photoSet.m_images[v];
+}
+int PatchManager::upload(const vector<Ppatch>& pp) {
+    vector<mvs_patch> recs;
+    recs.reserve(pp.size());
+    for (const Ppatch& p : pp) recs.push_back(to_record(*p));
+    return mvs_engine_upload_patches(m_pmmvps.m_engine, (int64_t)recs.size(), recs.data());
+}
+void PatchManager::addPatches(const vector<Ppatch>& seeds) { (void)upload(seeds); }
+int PatchManager::readPatches() { return readPatches(0); }
+int PatchManager::readPatches(const int iter) {  // patch_manager.cpp:435-497
+    char buffer[1024];
+    snprintf(buffer, sizeof buffer, "%sply/%08d.patch", m_pmmvps.m_prefix.c_str(), iter);
+    ifstream ifstr(buffer);
+    if (!ifstr.is_open()) return -1;
+    string header;
+    int pnum = 0;
+    ifstr >> header >> pnum;
+    vector<Ppatch> pp;
+    for (int p = 0; p < pnum; ++p) {
+        Ppatch ppatch(new Patch());
+        ifstr >> *ppatch;
+        ppatch->m_fix = 0;
+        ppatch->m_tmp = ppatch->score2(m_pmmvps.m_nccThreshold);
+        ppatch->m_vimages.clear();
+        image2index(*ppatch);
+        if (ppatch->m_images.empty()) break;
+        pp.push_back(ppatch);
+    }
+    return upload(pp);
+}
+void PatchManager::collectPatches(const int) {
+    m_ppatches.clear();
+    int64_t n = 0;
+    if (mvs_engine_download_patches(m_pmmvps.m_engine, 0, nullptr, &n) != 0 || n == 0) return;
+    vector<mvs_patch> recs((size_t)n);
+    if (mvs_engine_download_patches(m_pmmvps.m_engine, n, recs.data(), &n) != 0) return;
+    m_ppatches.reserve((size_t)n);
+    for (const mvs_patch& r : recs) m_ppatches.push_back(from_record(r));
+}
+void PatchManager::writePatches(const string prefix, bool bExportPLY, bool bExportPatch, bool) {
+    collectPatches(1);
+    if (bExportPLY) writePly(m_ppatches, prefix + ".ply");
+    if (bExportPatch) {
+        ofstream ofstr((prefix + ".patch").c_str());
+        ofstr << "PATCHES" << endl << (int)m_ppatches.size() << endl;
+        for (const Ppatch& pp : m_ppatches) { Patch patch = *pp; index2image(patch); ofstr << patch << "\n"; }
+    }
+}
+void PatchManager::writePly(const vector<Ppatch>& patches, const string filename) {
+    ofstream ofstr(filename.c_str());
+    ofstr << "ply\nformat ascii 1.0\nelement vertex " << (int)patches.size()
+          << "\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+             "property uchar diffuse_red\nproperty uchar diffuse_green\nproperty uchar diffuse_blue\nend_header\n";
+    for (const Ppatch& p : patches)
+        ofstr << p->m_coord[0] << ' ' << p->m_coord[1] << ' ' << p->m_coord[2] << ' ' << p->m_normal[0] << ' ' << p->m_normal[1] << ' '
+              << p->m_normal[2] << " 128 128 128\n";
+}
+
+// ------------------------------------------------------------------ Propagate
+void Propagate::init() {  // propagate.cpp:23-26
+    MAX_NUM_OF_PROPAG = 2;
+    MAX_NUM_OF_PATCHES = MAX_NUM_OF_PROPAG * m_pmmvps.m_csize * m_pmmvps.m_csize;
+}
+int Propagate::run(const int iter) {  // propagate.cpp:28-64: the drop-in boundary
+    m_ecount = m_fcount0 = m_fcount1 = m_pcount = 0;
+    int r = mvs_engine_set_thresholds(m_pmmvps.m_engine, m_pmmvps.m_nccThreshold, m_pmmvps.m_nccThresholdBefore, m_pmmvps.m_depth);
+    if (r == 0) r = mvs_engine_propagate(m_pmmvps.m_engine, iter, &m_counters);
+    if (r != 0) { cerr << "Propagate::run: " << mvs_last_error() << endl; return r; }
+    m_ecount = m_counters.patches; m_fcount0 = m_counters.fail0; m_fcount1 = m_counters.fail1;
+    m_pcount = m_counters.inserted + m_counters.replaced;
+    cerr << "total pass fail0 fail1 refinepatch: " << m_ecount << " " << m_pcount << " " << m_fcount0 << " " << m_fcount1 << " "
+         << m_pcount + m_fcount1 << endl;
+    return 0;
+}
+
+// ------------------------------------------------------------------ PmMvps
+PmMvps::PmMvps() : m_patchManager(*this), m_propagate(*this) {}
+PmMvps::~PmMvps() { if (m_engine) mvs_engine_destroy(m_engine); }
+
+int PmMvps::createEngine(float maxAngle, float quad) {
+    mvs_config cfg;
+    mvs_default_config(&cfg);
+    cfg.nviews = m_nimages; cfg.level = m_level; cfg.csize = m_csize; cfg.wsize = m_wsize;
+    cfg.minImageNum = m_minImageNumThreshold; cfg.nccThreshold = m_nccThreshold;
+    cfg.maxAngleThreshold = maxAngle; cfg.quadThreshold = quad;
+    cfg.depth = 0; cfg.seed = m_seed; cfg.refine_steps = m_refineSteps;
+    cfg.enable_check = 0;  // Optim::check (m_depth >= 2) is not in the engine yet
+    int r = mvs_engine_create(&cfg, &m_engine);
+    if (r != 0) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
+    vector<mvs_view_desc> views(m_nimages);
+    for (int i = 0; i < m_nimages; ++i) {
+        const Photo& ph = m_photoSet.m_photos[i];
+        views[i].width = ph.m_width; views[i].height = ph.m_height;
+        memcpy(views[i].P, ph.m_projection, sizeof views[i].P);
+        views[i].rgb = ph.m_image.data();
+        views[i].mask = ph.m_mask.empty() ? nullptr : ph.m_mask.data();
+    }
+    r = mvs_engine_set_views(m_engine, m_nimages, views.data());
+    if (r != 0) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
+    return 0;
+}
+
+int PmMvps::init(const Option& option, const PhotoSet& photos) {  // pmmvps.cpp:18-68
+    m_images = option.m_images; m_nimages = option.m_nimages; m_nillums = option.m_nillums;
+    m_prefix = option.m_prefix; m_level = option.m_level; m_csize = option.m_csize;
+    m_nccThreshold = option.m_nccThreshold; m_wsize = option.m_wsize; m_minImageNumThreshold = option.m_minImageNum;
+    m_visdata = option.m_visdata; m_visdata2 = option.m_visdata2;
+    m_tau = std::min(option.m_minImageNum * 2, m_nimages);
+    m_depth = 0;
+    m_photoSet = photos;
+    m_angleThreshold0 = (float)(60.0f * M_PI / 180.0f);
+    m_angleThreshold1 = (float)(60.0f * M_PI / 180.0f);
+    m_countThreshold1 = 4;
+    m_neighborThreshold = 0.5f; m_neighborThreshold1 = 1.0f; m_neighborThreshold2 = 1.0f;
+    m_nccThresholdBefore = m_nccThreshold - 0.3f;
+    m_maxAngleThreshold = option.m_maxAngleThreshold;
+    m_quadThreshold = option.m_quadThreshold;
+    if (int r = createEngine(option.m_maxAngleThreshold, option.m_quadThreshold)) return r;
+    m_patchManager.init();
+    m_propagate.init();
+    return 0;
+}
+int PmMvps::init(const Option& option) {
+    PhotoSet ps;
+    if (ps.init(option.m_images, option.m_prefix, option.m_nimages, option.m_nillums, option.m_level + 3, option.m_wsize, 1) != 0) return MVS_ERR_ARG;
+    return init(option, ps);
+}
+void PmMvps::updateThreshold() { m_nccThreshold -= 0.05f; m_nccThresholdBefore -= 0.05f; m_countThreshold1 = 2; }
+
+int PmMvps::run() {  // pmmvps.cpp:76-114
+    if (m_writeFiles) (void)m_patchManager.readPatches();  // DepthNormInit::createPatches, isTest branch (depth_normal_init.cpp:29-33)
+    ++m_depth;
+    for (int iter = 0; iter < ITER; ++iter) {
+        cerr << "\n---------------------\nIteration: " << iter << "\n---------------------" << endl;
+        if (int r = m_propagate.run(iter)) return r;
+        if (m_writeFiles) m_patchManager.writePatches(m_prefix + "ply/refined_patches_before_refine_" + std::to_string(iter), true, false, false);
+        // Filter::run (pmmvps.cpp:101) is outside the engine's current scope
+        updateThreshold();
+        ++m_depth;
+        if (m_writeFiles) m_patchManager.writePatches(m_prefix + "ply/refined_patches_" + std::to_string(iter), true, false, false);
+    }
+    return 0;
+}
+
+}  // namespace mvshost
+
+// ------------------------------------------------------------------ C entry used by the tests: run the mirror on in-memory inputs
+extern "C" int mvshost_run(int nviews, int width, int height, const float* P /*[n][12]*/, const unsigned char* rgb /*[n][H][W][3]*/,
+                           int level, int csize, int wsize, int minImageNum, float nccThreshold, unsigned seed, int iters,
+                           long long nseeds, const mvs_patch* seeds, long long cap, mvs_patch* out, long long* nout, long long* patches_total) {
+    using namespace mvshost;
+    Option option;
+    option.m_nimages = nviews; option.m_nillums = 1; option.m_level = level; option.m_csize = csize; option.m_wsize = wsize;
+    option.m_minImageNum = minImageNum; option.m_nccThreshold = nccThreshold; option.m_flag = -1;
+    for (int i = 0; i < nviews; ++i) option.m_images.push_back(i);
+    PhotoSet ps;
+    ps.m_images = option.m_images;
+    for (int i = 0; i < nviews; ++i) {
+        ps.m_dict[i] = i;
+        ps.setPhoto(i, width, height, P + 12 * i, rgb + (size_t)i * width * height * 3, nullptr);
+    }
+    PmMvps pmmvps;
+    pmmvps.m_seed = seed; pmmvps.ITER = iters; pmmvps.m_writeFiles = false;
+    if (int r = pmmvps.init(option, ps)) return r;
+    if (int r = mvs_engine_upload_patches(pmmvps.m_engine, nseeds, seeds)) return r;
+    long long total = 0;
+    ++pmmvps.m_depth;
+    for (int iter = 0; iter < iters; ++iter) {
+        if (int r = pmmvps.m_propagate.run(iter)) return r;
+        total += pmmvps.m_propagate.m_ecount;
+        pmmvps.updateThreshold();
+        ++pmmvps.m_depth;
+    }
+    pmmvps.m_patchManager.collectPatches();
+    const auto& pp = pmmvps.m_patchManager.m_ppatches;
+    *nout = (long long)pp.size();
+    for (long long i = 0; i < std::min<long long>(cap, (long long)pp.size()); ++i) out[i] = to_record(*pp[i]);
+    if (patches_total) *patches_total = total;
+    return 0;
+}
+
+// Option::init on a file: out_i = {nimages, level, csize, wsize, minImageNum, flag, #images}, out_f = {threshold, maxAngle, quad}
+extern "C" int mvshost_option_probe(const char* prefix, const char* option, int* out_i, float* out_f) {
+    mvshost::Option o;
+    const int r = o.init(prefix, option);
+    out_i[0] = o.m_nimages; out_i[1] = o.m_level; out_i[2] = o.m_csize; out_i[3] = o.m_wsize; out_i[4] = o.m_minImageNum;
+    out_i[5] = o.m_flag; out_i[6] = (int)o.m_images.size();
+    out_f[0] = o.m_nccThreshold; out_f[1] = o.m_maxAngleThreshold; out_f[2] = o.m_quadThreshold;
+    return r;
+}
+// Patch text format (patch.cpp:31-79): parse `text`, write it back into `out` (cap bytes); returns the length
+extern "C" int mvshost_patch_roundtrip(const char* text, char* out, int cap, mvs_patch* rec) {
+    std::istringstream is(text);
+    mvshost::Patch p;
+    is >> p;
+    if (rec) *rec = mvshost::to_record(p);
+    std::ostringstream os;
+    os << p;
+    const std::string s = os.str();
+    if ((int)s.size() + 1 > cap) return -1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+// Camera text (camera.cpp:27-63): returns the 3x4 projection
+extern "C" int mvshost_camera_probe(const char* cname, float* P12) {
+    mvshost::Photo ph;
+    const int r = ph.initCamera(cname);
+    memcpy(P12, ph.m_projection, sizeof ph.m_projection);
+    return r;
+}

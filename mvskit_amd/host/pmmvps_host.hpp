@@ -1,0 +1,170 @@
+// pmmvps_host.hpp -- host-side mirror of the reference's class surface for the propagate+optim path.
+//
+// Same class names, public fields and call sequence as imkaywu/MVSKit (test/test.cpp:155-161):
+//     Option option;  option.init(prefix, "option");
+//     PmMvps pmmvps;  pmmvps.init(option);  pmmvps.run();
+// but dependency-free (no Eigen / CImg / NLopt) and with Propagate::run forwarding to the MI355X engine
+// through the C ABI of include/mvskit_engine.h.  What stays on the host is what the reference keeps
+// around the hot path: option parsing (pmmvps/option.cpp), camera/image/patch file I/O
+// (image/camera.cpp:27-63, image/photoSet.cpp:20-61, pmmvps/patch.cpp:31-79,
+// pmmvps/patch_manager.cpp:435-540) and the iteration loop (pmmvps/pmmvps.cpp:76-114).
+#pragma once
+#include <array>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mvskit_engine.h"
+
+namespace mvshost {
+
+using std::string;
+using std::vector;
+typedef std::array<float, 4> Vector4f;
+
+// pmmvps/option.hpp:20-73
+struct Option {
+    Option();
+    // returns 0, or -1 with a message on std::cerr (the reference exit(1)s, option.cpp:113-128)
+    int init(const string prefix, const string option);
+
+    int m_nimages, m_nillums, m_level, m_csize;
+    float m_nccThreshold;
+    int m_wsize, m_minImageNum, m_cpu, m_setEdge, m_useBound, m_useVisData, m_sequence;
+    float m_maxAngleThreshold, m_quadThreshold;
+    string m_prefix, m_option;
+    int m_flag;
+    vector<int> m_images;
+    std::map<int, int> m_dict;
+    vector<vector<int> > m_visdata, m_visdata2;
+
+protected:
+    void initVisdata();
+};
+
+// image/photo.hpp + camera.hpp + image.hpp, reduced to what crosses the boundary: level-0 image and projection
+struct Photo {
+    int m_width = 0, m_height = 0;
+    float m_projection[12] = {0};       // Camera::m_projections[0], row-major 3x4
+    vector<unsigned char> m_image;      // Image::m_images[0], interleaved RGB
+    vector<unsigned char> m_mask;       // Image::m_masks[0] or empty
+    int m_txtType = 0;
+    // Camera::init for CONTOUR / CONTOUR2 text files (camera.cpp:27-63,102-141,241-261)
+    int initCamera(const string cname);
+    // binary PPM (P6) reader; PhotoSet::init accepts `image/%04d%04d.ppm` (photoSet.cpp:33-36)
+    int readPpm(const string iname);
+    int readPgmMask(const string mname);  // P5, thresholded at 127 (image.cpp:170-177)
+};
+
+// image/photoSet.hpp:23-62
+class PhotoSet {
+public:
+    int init(const vector<int>& images, const string prefix, const int nimages, const int nillums, const int maxLevel, const int size, const int alloc);
+    // in-memory injection (synthetic scenes)
+    void setPhoto(int index, int width, int height, const float P[12], const unsigned char* rgb, const unsigned char* mask);
+    int getWidth(const int index, const int level) const { return m_photos[index].m_width >> level; }
+    int getHeight(const int index, const int level) const { return m_photos[index].m_height >> level; }
+    int image2index(const int image) const;
+    vector<Photo> m_photos;
+    vector<int> m_images;
+    int m_nimages = 0, m_nillums = 1;
+    string m_prefix;
+    std::map<int, int> m_dict;
+};
+
+// pmmvps/patch.hpp:23-67
+class Patch {
+public:
+    Patch();
+    float score2(const float threshold) const;
+    Vector4f m_coord, m_normal;
+    vector<int> m_images, m_vimages;
+    float m_ncc;
+    int m_nimages, m_iter, m_collected, m_flag;
+    unsigned char m_dflag;
+    int m_fix, m_id;
+    float m_dscale, m_ascale, m_tmp;
+};
+typedef std::shared_ptr<Patch> Ppatch;
+std::istream& operator>>(std::istream& istr, Patch& rhs);        // patch.cpp:31-56
+std::ostream& operator<<(std::ostream& ostr, const Patch& rhs);  // patch.cpp:58-79
+
+class PmMvps;
+
+// pmmvps/patch_manager.hpp: the grids live on the device; the host keeps m_ppatches and the file formats
+class PatchManager {
+public:
+    explicit PatchManager(PmMvps& pmmvps) : m_pmmvps(pmmvps) {}
+    void init();
+    void image2index(Patch& patch);
+    void index2image(Patch& patch);
+    void collectPatches(const int target = 0);  // downloads the pool (patch_manager.cpp:75-105)
+    int readPatches();                          // ply/00000000.patch -> engine (patch_manager.cpp:435-466)
+    int readPatches(const int iter);
+    void addPatches(const vector<Ppatch>& seeds);  // in-memory seeds
+    void writePatches(const string prefix, bool bExportPLY, bool bExportPatch, bool bExportPSet);  // :499-540
+    void writePly(const vector<Ppatch>& ppatches, const string filename);                           // :542-633, colour = 128 grey
+    vector<int> m_gheights, m_gwidths;
+    vector<Ppatch> m_ppatches;
+
+protected:
+    int upload(const vector<Ppatch>& pp);
+    PmMvps& m_pmmvps;
+};
+
+// pmmvps/propagate.hpp:29-69
+class Propagate {
+public:
+    explicit Propagate(PmMvps& pmmvps) : m_pmmvps(pmmvps) {}
+    void init();
+    int run(const int iter);
+    int MAX_NUM_OF_PATCHES = 0, MAX_NUM_OF_PROPAG = 0;
+    long long m_ecount = 0, m_fcount0 = 0, m_fcount1 = 0, m_pcount = 0;
+    mvs_counters m_counters{};
+
+protected:
+    PmMvps& m_pmmvps;
+};
+
+// pmmvps/pmmvps.hpp:25-107
+class PmMvps {
+public:
+    PmMvps();
+    virtual ~PmMvps();
+    // returns 0 or a negative mvs_status (the reference exit(1)s)
+    int init(const Option& option);
+    int init(const Option& option, const PhotoSet& photos);  // photos already in memory
+    int run();
+    int ITER = 3;  // pmmvps.cpp:90 (compile-time constant there; D13)
+
+    int m_nimages = 0, m_nillums = 1;
+    vector<int> m_images;
+    string m_prefix;
+    int m_level = 1, m_csize = 2;
+    float m_nccThreshold = 0.7f;
+    int m_wsize = 7, m_minImageNumThreshold = 3;
+    vector<vector<int> > m_visdata, m_visdata2;
+    float m_quadThreshold = 2.5f;
+    int m_tau = 0, m_depth = 0;
+    float m_angleThreshold0 = 0, m_angleThreshold1 = 0;
+    int m_countThreshold1 = 4;
+    float m_neighborThreshold = 0.5f, m_neighborThreshold1 = 1.0f, m_neighborThreshold2 = 1.0f;
+    float m_nccThresholdBefore = 0.4f, m_maxAngleThreshold = 0;
+
+    PhotoSet m_photoSet;
+    PatchManager m_patchManager;
+    Propagate m_propagate;
+    mvs_engine* m_engine = nullptr;  // Optim + the PatchManager grids live behind this handle
+    unsigned m_seed = 1;
+    int m_refineSteps = 8;
+    bool m_writeFiles = true;
+
+    void updateThreshold();  // pmmvps.cpp:70-74
+
+protected:
+    int createEngine(float maxAngle, float quad);
+};
+
+}  // namespace mvshost

@@ -1,0 +1,114 @@
+"""Host-side mirror of the reference classes (mvskit_amd/host): option / camera / patch text formats on CPU,
+and the whole Option -> PmMvps::init -> run sequence against the oracle on the GPU."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+from mvskit_amd import build, engine, synth
+
+
+@pytest.fixture(scope="module")
+def host():
+    build.build_engine()
+    engine.load_library()  # loads torch's HIP runtime first, then libmvskit_engine.so
+    L = C.CDLL(build.build_host())
+    L.mvshost_option_probe.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
+    L.mvshost_patch_roundtrip.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p]
+    L.mvshost_camera_probe.argtypes = [C.c_char_p, C.c_void_p]
+    L.mvshost_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint,
+                              C.c_int, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+def test_option_file(host, tmp_path):
+    # keys and defaults of pmmvps/option.cpp:19-33,53-116
+    (tmp_path / "option").write_text("# comment line\nlevel 0\ncsize 2\nthreshold 0.65\nwsize 7\nminImageNum 2\nCPU 8\nmaxAngle 12\nquad 2.0\nimages -1 0 5\n")
+    oi, of = np.zeros(7, np.int32), np.zeros(3, np.float32)
+    assert host.mvshost_option_probe(str(tmp_path).encode() + b"/", b"option", oi.ctypes.data, of.ctypes.data) == 0
+    assert list(oi) == [5, 0, 2, 7, 2, -1, 5]
+    np.testing.assert_allclose(of, [0.65, 12 * math.pi / 180, 2.0], rtol=1e-6)
+    (tmp_path / "bad").write_text("level 1\nnosuchkey 3\nimages 2 0 1\n")
+    assert host.mvshost_option_probe(str(tmp_path).encode() + b"/", b"bad", oi.ctypes.data, of.ctypes.data) == -1  # option.cpp:117-120
+    (tmp_path / "noimages").write_text("level 1\n")
+    assert host.mvshost_option_probe(str(tmp_path).encode() + b"/", b"noimages", oi.ctypes.data, of.ctypes.data) == -1  # option.cpp:125-128
+    (tmp_path / "defaults").write_text("images 3 4 7 9\n")
+    assert host.mvshost_option_probe(str(tmp_path).encode() + b"/", b"defaults", oi.ctypes.data, of.ctypes.data) == 0
+    assert list(oi) == [3, 1, 2, 7, 3, 3, 3]
+    np.testing.assert_allclose(of, [0.7, 10 * math.pi / 180, 2.5], rtol=1e-6)
+
+
+def test_patch_text_roundtrip(host):
+    # pmmvps/patch.cpp:31-79
+    text = b"PATCHES\n0.5 -1.25 2 1\n0 0.6 0.8 0\n0.91 0.015 0.3\n3\n2 0 5 \n2\n1 4 \n"
+    out = C.create_string_buffer(1024)
+    rec = np.zeros(1, dtype=engine.PATCH_DTYPE)
+    n = host.mvshost_patch_roundtrip(text, out, 1024, rec.ctypes.data)
+    assert n > 0
+    toks = out.value.decode().split()
+    assert toks == text.decode().split()
+    r = rec[0]
+    np.testing.assert_allclose(r["coord"], [0.5, -1.25, 2, 1])
+    np.testing.assert_allclose(r["normal"], [0, 0.6, 0.8, 0])
+    assert (r["nimages"], r["nvimages"]) == (3, 2) and list(r["images"][:3]) == [2, 0, 5] and list(r["vimages"][:2]) == [1, 4]
+    # PATCHA carries a type and a direction that are skipped (patch.cpp:37-41)
+    texta = b"PATCHA\n1 2 3 1\n0 0 1 0\n0.5 0.1 0.2\n7 0 0 1 0\n1\n3 \n0\n\n"
+    n = host.mvshost_patch_roundtrip(texta, out, 1024, rec.ctypes.data)
+    assert n > 0 and rec[0]["nimages"] == 1 and rec[0]["images"][0] == 3
+
+
+def test_camera_text(host, tmp_path):
+    P = np.arange(12, dtype=np.float32) * 0.5 + 1
+    (tmp_path / "c0.txt").write_text("CONTOUR\n" + " ".join(str(float(v)) for v in P) + "\n")
+    got = np.zeros(12, np.float32)
+    assert host.mvshost_camera_probe(str(tmp_path / "c0.txt").encode(), got.ctypes.data) == 0
+    np.testing.assert_array_equal(got, P)  # camera.cpp:110-116
+    # CONTOUR2 with the intrinsics of the sample camera in test/test.cpp:96-100 and Euler angles (degrees) + t
+    fx = fy = 765.702941895
+    skew, cx, cy = 0.0200504438012, 320.0, 240.0
+    a, b, g = 10.0, -20.0, 30.0
+    t = [-0.959477365017, 0.0510520711541, 0.251982748508]
+    (tmp_path / "c2.txt").write_text(f"CONTOUR2\n{fx} {fy} {skew} {cx} {cy} 0\n{a} {b} {g} {t[0]} {t[1]} {t[2]}\n")
+    assert host.mvshost_camera_probe(str(tmp_path / "c2.txt").encode(), got.ctypes.data) == 0
+    ar, br, gr = map(math.radians, (a, b, g))
+    s1, s2, s3, c1, c2, c3 = math.sin(ar), math.sin(br), math.sin(gr), math.cos(ar), math.cos(br), math.cos(gr)
+    R = np.array([[c2 * c3, c3 * s2 * s1 - s3 * c1, c3 * s2 * c1 + s3 * s1], [s3 * c2, s3 * s2 * s1 + c3 * c1, s3 * s2 * c1 - c3 * s1],
+                  [-s2, c2 * s1, c2 * c1]])  # Camera::quat2proj, camera.cpp:241-261
+    K = np.array([[fx, skew, cx], [0, fy, cy], [0, 0, 1]])
+    exp = K @ np.concatenate([R, np.array(t)[:, None]], 1)
+    np.testing.assert_allclose(got.reshape(3, 4), exp, rtol=2e-5, atol=1e-4)
+    (tmp_path / "bad.txt").write_text("CONTOUR9\n1 2 3\n")
+    assert host.mvshost_camera_probe(str(tmp_path / "bad.txt").encode(), got.ctypes.data) == -1  # camera.cpp:45-48
+
+
+@pytest.mark.gpu
+def test_pmmvps_run_matches_oracle(host, small_plane_scene):
+    import oracle_binding as ob
+
+    sc = small_plane_scene
+    seeds = synth.make_seeds(sc, stride=4, seed=21)
+    iters = 2
+    o = ob.Oracle(sc.nviews, level=0, minImageNum=2, enable_check=0, seed=9, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64, nthreads=8,
+                  depth=1)
+    o.set_scene(sc)
+    o.add_patches(seeds)
+    total = 0
+    for it in range(iters):
+        total += o.propagate(it)["patches"]
+        o.update_threshold()  # PmMvps::updateThreshold + ++m_depth (pmmvps.cpp:103-105)
+    po = o.patches()
+    out = np.zeros(po.shape[0] + 1000, dtype=engine.PATCH_DTYPE)
+    nout, ptot = C.c_longlong(), C.c_longlong()
+    P = np.ascontiguousarray(sc.P, dtype=np.float32)
+    img = np.ascontiguousarray(sc.images)
+    sd = np.ascontiguousarray(seeds)
+    r = host.mvshost_run(sc.nviews, sc.W, sc.H, P.ctypes.data, img.ctypes.data, 0, 2, 7, 2, C.c_float(0.7), 9, iters, sd.shape[0], sd.ctypes.data,
+                         out.shape[0], out.ctypes.data, C.byref(nout), C.byref(ptot))
+    assert r == 0
+    assert ptot.value == total and nout.value == po.shape[0]
+    pe = out[: nout.value]
+    np.testing.assert_array_equal(pe["images"], po["images"])
+    np.testing.assert_allclose(pe["coord"], po["coord"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(pe["normal"], po["normal"], rtol=0, atol=1e-3)
