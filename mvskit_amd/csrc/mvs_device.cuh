@@ -38,6 +38,11 @@ DEV F4 mul4(F4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
 DEV F4 div4(F4 a, float s) { return {a.x / s, a.y / s, a.z / s, a.w / s}; }
 DEV F3 sub3(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 DEV F3 div3(F3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+// v / |v| as v * (1/|v|) (Eigen 3.2 vector / scalar semantics; one IEEE division instead of three or four)
+DEV F4 nrm4(F4 a) { const float inv = 1.0f / norm4(a); return {a.x * inv, a.y * inv, a.z * inv, a.w * inv}; }
+DEV F3 nrm3(F3 a) { const float inv = 1.0f / norm3(a); return {a.x * inv, a.y * inv, a.z * inv}; }
+DEV F4 scl4(F4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+DEV F3 scl3(F3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 DEV F3 cross3(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 DEV F4 ld4(const float* p) { return {p[0], p[1], p[2], p[3]}; }
 DEV F3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
@@ -52,16 +57,16 @@ DEV float wave_sum(float x) {
     x = x + dpp_f<0x4E>(x);   // quad_perm [2,3,0,1]   : i ^ 2
     x = x + dpp_f<0x141>(x);  // row_half_mirror       : other quad of the 8 (== i ^ 4 once quads are uniform)
     x = x + dpp_f<0x140>(x);  // row_mirror            : other half of the row of 16 (== i ^ 8)
-    x = x + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));  // i ^ 16
-    return rlf(x, 0) + rlf(x, 32);                                                    // i ^ 32
+    // every row of 16 now holds its row sum in all lanes: i ^ 16 pairs rows (0,1) and (2,3), i ^ 32 the two halves.
+    // Four v_readlane instead of a ds_swizzle: no trip through the LDS pipeline, same additions.
+    return (rlf(x, 0) + rlf(x, 16)) + (rlf(x, 32) + rlf(x, 48));
 }
 DEV float wave_min(float x) {
     x = fminf(x, dpp_f<0xB1>(x));
     x = fminf(x, dpp_f<0x4E>(x));
     x = fminf(x, dpp_f<0x141>(x));
     x = fminf(x, dpp_f<0x140>(x));
-    x = fminf(x, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F)));
-    return fminf(rlf(x, 0), rlf(x, 32));
+    return fminf(fminf(rlf(x, 0), rlf(x, 16)), fminf(rlf(x, 32), rlf(x, 48)));
 }
 
 // ------------------------------------------------------------------ deterministic libm subset
@@ -152,7 +157,8 @@ DEV F3 project(const DView* vw, F4 X, int level) {
     float r2 = fma_(P[11], X.w, fma_(P[10], X.z, fma_(P[9], X.y, P[8] * X.x)));
     if (r2 <= 0.0f) return {-65535.0f, -65535.0f, -1.0f};
     const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
-    F3 ic{r0 / r2, r1 / r2, 1.0f};
+    const float inv = 1.0f / r2;
+    F3 ic{r0 * inv, r1 * inv, 1.0f};
     ic.x = fmaxf(lo, fminf(hi, ic.x));
     ic.y = fmaxf(lo, fminf(hi, ic.y));
     return ic;
@@ -165,12 +171,12 @@ DEV F4 unproject(const DView* vw, F3 ic, int level) {
     return {fma_(M[2], b.z, fma_(M[1], b.y, M[0] * b.x)), fma_(M[5], b.z, fma_(M[4], b.y, M[3] * b.x)),
             fma_(M[8], b.z, fma_(M[7], b.y, M[6] * b.x)), 1.0f};
 }
-// Optim::getUnit, optim.cpp:34-41 (double expression)
+// Optim::getUnit, optim.cpp:34-41 (2 * fz * 2^level is exact, so one fp32 division; see the oracle)
 DEV float get_unit(const DParams& prm, const DView* vw, F4 coord) {
     const float fz = norm4(sub4(coord, ld4(vw->center)));
     const float ips = vw->ipscale;
     if (ips == 0.0f) return 1.0f;
-    return (float)(2.0 * (double)fz * (double)(1 << prm.level) / (double)ips);
+    return (2.0f * fz * (float)(1 << prm.level)) / ips;
 }
 // PatchManager::setGrids cell rule, patch_manager.cpp:241-250
 DEV void cell_of(const DParams& prm, const DView* vw, F4 coord, int& ix, int& iy) {
@@ -183,15 +189,15 @@ DEV void get_paxes(const DParams& prm, const DView* vw, F4 coord, F4 normal, F4&
     const float pscale = get_unit(prm, vw, coord);
     F3 n3{normal.x, normal.y, normal.z};
     F3 y3 = cross3(n3, ld3(vw->xaxis));
-    y3 = div3(y3, norm3(y3));
+    y3 = nrm3(y3);
     F3 x3 = cross3(y3, n3);
     px = {x3.x * pscale, x3.y * pscale, x3.z * pscale, 0.0f};
     py = {y3.x * pscale, y3.y * pscale, y3.z * pscale, 0.0f};
     const F3 c0 = project(vw, coord, prm.level);
     const float xdis = norm3(sub3(project(vw, add4(coord, px), prm.level), c0));
     const float ydis = norm3(sub3(project(vw, add4(coord, py), prm.level), c0));
-    px = div4(px, xdis);
-    py = div4(py, ydis);
+    px = scl4(px, 1.0f / xdis);
+    py = scl4(py, 1.0f / ydis);
 }
 DEV float robustincc(float incc) { return incc / (1 + 3 * incc); }
 DEV float unrobustincc(float r) { return r / (1 - 3 * r); }
@@ -218,7 +224,7 @@ DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, b
     if (!active) return f;
     const DView* vw = prm.views + v;
     F4 ray = sub4(ld4(vw->center), coord);
-    ray = div4(ray, norm4(ray));
+    ray = nrm4(ray);
     const float weight = fmaxf(0.0f, dot4(ray, pz));
     if (weight < prm.cosAngle1) return f;
     F3 center = project(vw, coord, prm.level);
@@ -228,9 +234,10 @@ DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, b
     const int ld = level_diff(prm, ratio);
     const float scale = pow2_level(ld);
     const int newLevel = prm.level + ld;
-    center = div3(center, scale);
-    dx = div3(dx, scale);
-    dy = div3(dy, scale);
+    const float iscale = pow2_level(-ld);  // exact reciprocal of a power of two
+    center = scl3(center, iscale);
+    dx = scl3(dx, iscale);
+    dy = scl3(dy, iscale);
     // Optim::getTexSafe, optim.cpp:895-915
     const float m = (float)(prm.wsize / 2);
     const float tlx = (center.x - dx.x * m) - dy.x * m, trx = (center.x + dx.x * m) - dy.x * m;
@@ -282,12 +289,11 @@ DEV bool tex_sample_norm(const DParams& prm, WaveCtx& wc, const Frame& f, int j,
         b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
     }
     wc.view_evals++;
-    const float sz = (float)prm.wsz;
-    const float a0 = wave_sum(r) / sz, a1 = wave_sum(g) / sz, a2 = wave_sum(b) / sz;
+    const float a0 = wave_sum(r) * prm.inv_sz, a1 = wave_sum(g) * prm.inv_sz, a2 = wave_sum(b) * prm.inv_sz;
     float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
     if (wc.sample_lane) { d0 = r - a0; d1 = g - a1; d2 = b - a2; }
     const float ssd = wave_sum(fma_(d2, d2, fma_(d1, d1, d0 * d0)));
-    float msd = sqrtf(ssd / (float)(3 * prm.wsz));
+    float msd = sqrtf(ssd * prm.inv_3sz);
     if (msd == 0.0f) msd = 1.0f;
     const float inv = 1.0f / msd;
     t0 = d0 * inv; t1 = d1 * inv; t2 = d2 * inv;
@@ -295,7 +301,7 @@ DEV bool tex_sample_norm(const DParams& prm, WaveCtx& wc, const Frame& f, int j,
 }
 // Optim::dot, optim.cpp:601-609
 DEV float tex_dot(const DParams& prm, float a0, float a1, float a2, float b0, float b1, float b2) {
-    return wave_sum(fma_(a2, b2, fma_(a1, b1, a0 * b0))) / (float)(3 * prm.wsz);
+    return wave_sum(fma_(a2, b2, fma_(a1, b1, a0 * b0))) * prm.inv_3sz;
 }
 
 // ------------------------------------------------------------------ candidate patch (registers)
@@ -315,7 +321,7 @@ DEV float compute_weights(const DParams& prm, const WaveCtx& wc, F4 coord, F4 no
         const DView* vw = prm.views + img;
         unit = get_unit(prm, vw, coord);
         F4 ray = sub4(ld4(vw->center), coord);
-        ray = div4(ray, norm4(ray));
+        ray = nrm4(ray);
         const float d = dot4(ray, normal);
         if (0.0f < d) unit /= d; else unit = (float)(INT_MAX / 2);
     }
@@ -395,7 +401,7 @@ DEV void add_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c
         const F3 ic = project(vw, c.coord, prm.level);
         if (!(ic.x < 0.0f || vw->W[prm.level] - 1 <= ic.x || ic.y < 0.0f || vw->H[prm.level] - 1 <= ic.y)) {
             F4 ray = sub4(ld4(vw->center), c.coord);
-            ray = div4(ray, norm4(ray));
+            ray = nrm4(ray);
             q = prm.cosAngle0 <= dot4(ray, c.normal);
         }
     }
@@ -424,7 +430,7 @@ DEV void sort_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& 
     if (wc.lane < c.nimg) {  // computeUnits(patch, indexes, units, rays), optim.cpp:86-107
         const DView* vw = prm.views + c.img;
         ray = sub4(ld4(vw->center), c.coord);
-        ray = div4(ray, norm4(ray));
+        ray = nrm4(ray);
         const float d = dot4(ray, c.normal);
         valid = !(d <= 0.0f);
         if (valid) unit = get_unit(prm, vw, c.coord) / d;
@@ -464,7 +470,7 @@ DEV void set_scales(const DParams& prm, const WaveCtx& wc, Cand& c) {
     const float unit = get_unit(prm, rv, c.coord);
     const float unit2 = 2.0f * unit;
     F4 ray = sub4(c.coord, ld4(rv->center));
-    ray = div4(ray, norm4(ray));
+    ray = nrm4(ray);
     const int num = min(prm.tau, c.nimg);
     float dn = 0.0f;
     if (wc.lane >= 1 && wc.lane < num) {
@@ -484,7 +490,7 @@ DEV int check_angles(const DParams& prm, const WaveCtx& wc, const Cand& c) {
     F4 ray{0, 0, 0, 0};
     if (wc.lane < c.nimg) {
         ray = sub4(ld4((prm.views + c.img)->center), c.coord);
-        ray = div4(ray, norm4(ray));
+        ray = nrm4(ray);
     }
     int count = 0;
     for (int j = 1; j < c.nimg; ++j) {
@@ -569,7 +575,7 @@ DEV void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, uin
     rc.center = c.coord;
     rc.ref = rli(c.img, 0);
     rc.ray = sub4(c.coord, ld4((prm.views + rc.ref)->center));
-    rc.ray = div4(rc.ray, norm4(rc.ray));
+    rc.ray = nrm4(rc.ray);
     rc.dscale = c.dscale;
     rc.ascale = prm.ascaleConst;
     const float w = compute_weights(prm, wc, c.coord, c.normal, c.img, c.nimg);
@@ -609,7 +615,7 @@ DEV void filter_images_by_angle(const DParams& prm, const WaveCtx& wc, int* scra
     bool bad = false;
     if (wc.lane < c.nimg) {
         F4 ray = sub4(ld4((prm.views + c.img)->center), c.coord);
-        ray = div4(ray, norm4(ray));
+        ray = nrm4(ray);
         bad = dot4(ray, c.normal) < prm.cosAngle1;
     }
     const unsigned long long bm = ballot(bad);
@@ -684,7 +690,7 @@ DEV int is_visible(const DParams& prm, const Cand& c, int image, int ix, int iy,
     const DPatch* q = prm.pool + (uint32_t)(dp & 0xffffffffull);
     const F4 qc = ld4(q->coord);
     F4 ray = sub4(c.coord, ld4(vw->center));
-    ray = div4(ray, norm4(ray));
+    ray = nrm4(ray);
     const float diff = dot4(ray, sub4(c.coord, qc));
     const double factor = fmin(2.0, 2.0 + (double)dot4(ray, c.normal));
     const float lhs = get_unit(prm, vw, c.coord) * (float)prm.csize * strict;

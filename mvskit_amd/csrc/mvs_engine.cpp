@@ -114,6 +114,8 @@ void derive_params(mvs_engine* e) {  // PmMvps::init, pmmvps.cpp:32-36,54-67
     p.cosNeighbor120 = (float)cos(d120);
     p.sortThreshold = (float)(1.0f - cos(d10));
     p.ascaleConst = (float)(M_PI / 48.0f);
+    p.inv_sz = 1.0f / (float)(c.wsize * c.wsize);
+    p.inv_3sz = 1.0f / (float)(3 * c.wsize * c.wsize);
     p.neighborThreshold = 0.5f; p.neighborThreshold1 = 1.0f;
     p.quadThreshold = c.quadThreshold;
 }

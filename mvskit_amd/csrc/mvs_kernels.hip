@@ -492,8 +492,7 @@ __global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, co
     } else if (op == 4) {
         RefineCtx rc;
         rc.center = c.coord; rc.ref = rli(c.img, 0);
-        rc.ray = sub4(c.coord, ld4((prm.views + rc.ref)->center));
-        rc.ray = div4(rc.ray, norm4(rc.ray));
+        rc.ray = nrm4(sub4(c.coord, ld4((prm.views + rc.ref)->center)));
         rc.dscale = c.dscale; rc.ascale = prm.ascaleConst;
         float x[3];
         encode(prm, rc, c.coord, c.normal, x);

@@ -47,6 +47,7 @@ struct DParams {
     float nccThreshold, nccThresholdBefore;
     float cosAngle0, cosAngle1, cosMinAngle, cosMaxAngle, cosNeighborTypo, cosNeighbor120;
     float sortThreshold, ascaleConst, neighborThreshold, neighborThreshold1, quadThreshold;
+    float inv_sz, inv_3sz;  // 1/wsize^2 and 1/(3 wsize^2)
     int32_t total_cells;
     const DView* views;
     DPatch* pool;

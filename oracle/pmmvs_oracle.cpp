@@ -63,6 +63,11 @@ inline V3 sub3(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b
 inline V3 add3(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline V3 mul3(const V3& a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline V3 div3(const V3& a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+/* v / |v| as v * (1/|v|): Eigen 3.2 evaluates vector / scalar as a multiplication by the inverse */
+inline V4 nrm4(const V4& a) { const float inv = 1.0f / norm4(a); return {a.x * inv, a.y * inv, a.z * inv, a.w * inv}; }
+inline V3 nrm3(const V3& a) { const float inv = 1.0f / norm3(a); return {a.x * inv, a.y * inv, a.z * inv}; }
+inline V4 scl4(const V4& a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+inline V3 scl3(const V3& a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline V3 cross3(const V3& a, const V3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
 /* ------------------------------------------------------------------ deterministic libm subset
@@ -204,6 +209,7 @@ struct Scene {
     float cosNeighborTypo, cosNeighbor120;       /* pmmvps.cpp:124 (typo kept, D6) and :150 */
     float sortThreshold;                         /* optim.cpp:222 */
     float ascaleConst;                           /* optim.cpp:487 */
+    float inv_sz, inv_3sz;                       /* 1/(wsize^2), 1/(3 wsize^2): the means of optim.cpp:924,932,608 as multiplications */
     int depth = 0;
     std::vector<View> views;
     std::vector<Patch> pool;
@@ -235,7 +241,8 @@ inline V3 project(const View& vw, const V4& X, int level) {
     float r1 = fma_(P[7], X.w, fma_(P[6], X.z, fma_(P[5], X.y, P[4] * X.x)));
     float r2 = fma_(P[11], X.w, fma_(P[10], X.z, fma_(P[9], X.y, P[8] * X.x)));
     if (r2 <= 0.0f) return {-65535.0f, -65535.0f, -1.0f};
-    V3 ic{r0 / r2, r1 / r2, 1.0f};
+    const float inv = 1.0f / r2; /* icoord / icoord(2), camera.cpp:318, as a multiplication by the inverse */
+    V3 ic{r0 * inv, r1 * inv, 1.0f};
     const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
     ic.x = std::max(lo, std::min(hi, ic.x));
     ic.y = std::max(lo, std::min(hi, ic.y));
@@ -381,12 +388,13 @@ inline float reduce(const Scene& s, const float* a64, int n) {
 }
 
 /* ------------------------------------------------------------------ Optim (pmmvps/optim.cpp) */
-/* Optim::getUnit, optim.cpp:34-41 (the expression is evaluated in double) */
+/* Optim::getUnit, optim.cpp:34-41.  The reference evaluates 2.0 * fz * 2^level / ipscale in double and rounds to float;
+ * 2 * fz * 2^level is exact, so one fp32 division gives the same value except for double-rounding ties. */
 inline float get_unit(const Scene& s, int v, const V4& coord) {
     const View& vw = s.views[v];
     const float fz = norm4(sub4(coord, vw.center));
     if (vw.ipscale == 0.0f) return 1.0f;
-    return (float)(2.0 * fz * (0x0001 << s.cfg.level) / vw.ipscale);
+    return (2.0f * fz * (float)(0x0001 << s.cfg.level)) / vw.ipscale;
 }
 
 /* Optim::getPAxes, optim.cpp:67-84 */
@@ -395,15 +403,15 @@ void get_paxes(const Scene& s, int v, const V4& coord, const V4& normal, V4& px,
     const float pscale = get_unit(s, v, coord);
     V3 n3{normal.x, normal.y, normal.z};
     V3 y3 = cross3(n3, vw.xaxis);
-    y3 = div3(y3, norm3(y3));
+    y3 = nrm3(y3);
     V3 x3 = cross3(y3, n3);
     px = {x3.x * pscale, x3.y * pscale, x3.z * pscale, 0.0f};
     py = {y3.x * pscale, y3.y * pscale, y3.z * pscale, 0.0f};
     const V3 c0 = project(vw, coord, s.cfg.level);
     const float xdis = norm3(sub3(project(vw, add4(coord, px), s.cfg.level), c0));
     const float ydis = norm3(sub3(project(vw, add4(coord, py), s.cfg.level), c0));
-    px = div4(px, xdis);
-    py = div4(py, ydis);
+    px = scl4(px, 1.0f / xdis);
+    py = scl4(py, 1.0f / ydis);
 }
 
 inline float robustincc(float incc) { return incc / (1 + 3 * incc); }      /* optim.cpp:622-624 */
@@ -448,7 +456,7 @@ int get_tex(const Scene& s, const V4& coord, const V4& px, const V4& py, const V
     const View& vw = s.views[v];
     const int size = s.cfg.wsize;
     V4 ray = sub4(vw.center, coord);
-    ray = div4(ray, norm4(ray));
+    ray = nrm4(ray);
     const float weight = std::max(0.0f, dot4(ray, pz));
     if (weight < s.cosAngle1) return -1;
     const int margin = size / 2;
@@ -459,9 +467,10 @@ int get_tex(const Scene& s, const V4& coord, const V4& px, const V4& py, const V
     const int ld = level_diff(s, ratio);
     const float scale = pow2_level(ld);
     const int newLevel = s.cfg.level + ld;
-    center = div3(center, scale);
-    dx = div3(dx, scale);
-    dy = div3(dy, scale);
+    const float iscale = 1.0f / scale; /* power of two: exact */
+    center = scl3(center, iscale);
+    dx = scl3(dx, iscale);
+    dy = scl3(dy, iscale);
     if (get_tex_safe(s, v, size, center, dx, dy, newLevel) == -1) return -1;
     const float m = (float)margin;
     const V3 tl{(center.x - dx.x * m) - dy.x * m, (center.y - dx.y * m) - dy.y * m, 0.0f};
@@ -483,7 +492,7 @@ int get_tex(const Scene& s, const V4& coord, const V4& px, const V4& py, const V
 void normalize_tex(const Scene& s, Tex& tex) {
     const int sz = s.cfg.wsize * s.cfg.wsize;
     float ave[3];
-    for (int c = 0; c < 3; ++c) ave[c] = reduce(s, tex.c[c], sz) / sz;
+    for (int c = 0; c < 3; ++c) ave[c] = reduce(s, tex.c[c], sz) * s.inv_sz;
     float sq[64];
     for (int i = 0; i < 64; ++i) sq[i] = 0.0f;
     for (int i = 0; i < sz; ++i) {
@@ -492,7 +501,7 @@ void normalize_tex(const Scene& s, Tex& tex) {
         sq[i] = fma_(d2, d2, fma_(d1, d1, d0 * d0));
     }
     const float ssd = reduce(s, sq, sz);
-    float msd = sqrtf(ssd / (3 * sz));
+    float msd = sqrtf(ssd * s.inv_3sz);
     if (msd == 0.0f) msd = 1.0f;
     const float inv = 1.0f / msd; /* tex / msd as multiply by the inverse (Eigen 3.2 vector/scalar) */
     for (int i = 0; i < sz; ++i) for (int c = 0; c < 3; ++c) tex.c[c][i] *= inv;
@@ -504,7 +513,7 @@ float dot_tex(const Scene& s, const Tex& a, const Tex& b) {
     float p[64];
     for (int i = 0; i < 64; ++i) p[i] = 0.0f;
     for (int i = 0; i < sz; ++i) p[i] = fma_(a.c[2][i], b.c[2][i], fma_(a.c[1][i], b.c[1][i], a.c[0][i] * b.c[0][i]));
-    return reduce(s, p, sz) / (3 * sz);
+    return reduce(s, p, sz) * s.inv_3sz;
 }
 
 /* Optim::computeUnits(patch, units), optim.cpp:109-132, then computeWeights, optim.cpp:942-948 */
@@ -512,7 +521,7 @@ void compute_weights(const Scene& s, const V4& coord, const V4& normal, const in
     for (int i = 0; i < n; ++i) {
         float unit = get_unit(s, img[i], coord);
         V4 ray = sub4(s.views[img[i]].center, coord);
-        ray = div4(ray, norm4(ray));
+        ray = nrm4(ray);
         const float d = dot4(ray, normal);
         if (0.0f < d) unit /= d; else unit = (float)(INT_MAX / 2);
         w[i] = unit;
@@ -625,7 +634,7 @@ void add_images(const Scene& s, Patch& p) {
         const V3 ic = project(vw, p.coord, s.cfg.level);
         if (ic.x < 0.0f || vw.W[s.cfg.level] - 1 <= ic.x || ic.y < 0.0f || vw.H[s.cfg.level] - 1 <= ic.y) continue;
         V4 ray = sub4(vw.center, p.coord);
-        ray = div4(ray, norm4(ray));
+        ray = nrm4(ray);
         if (s.cosAngle0 <= dot4(ray, p.normal) && p.nimg < LISTCAP) p.img[p.nimg++] = v;
     }
 }
@@ -647,7 +656,7 @@ void sort_images(const Scene& s, Patch& p) {
     V4 rays0[MAXI];
     for (int i = 0; i < p.nimg; ++i) { /* computeUnits(patch, indexes, units, rays), optim.cpp:86-107 */
         V4 ray = sub4(s.views[p.img[i]].center, p.coord);
-        ray = div4(ray, norm4(ray));
+        ray = nrm4(ray);
         const float d = dot4(ray, p.normal);
         if (d <= 0.0f) continue;
         idx0[n0] = p.img[i]; units0[n0] = get_unit(s, p.img[i], p.coord) / d; rays0[n0] = ray; ++n0;
@@ -675,7 +684,7 @@ void set_scales(const Scene& s, Patch& p) {
     const float unit = get_unit(s, p.img[0], p.coord);
     const float unit2 = 2.0f * unit;
     V4 ray = sub4(p.coord, s.views[p.img[0]].center);
-    ray = div4(ray, norm4(ray));
+    ray = nrm4(ray);
     const int num = std::min(s.tau, p.nimg);
     for (int i = 1; i < num; ++i) {
         const View& vw = s.views[p.img[i]];
@@ -690,7 +699,7 @@ void set_scales(const Scene& s, Patch& p) {
 /* PhotoSet::checkAngles, photoSet.cpp:77-103; minAngle < acos(dot) < maxAngle as cosine compares */
 int check_angles(const Scene& s, const V4& coord, const int* idx, int n) {
     V4 rays[MAXI];
-    for (int i = 0; i < n; ++i) { rays[i] = sub4(s.views[idx[i]].center, coord); rays[i] = div4(rays[i], norm4(rays[i])); }
+    for (int i = 0; i < n; ++i) { rays[i] = sub4(s.views[idx[i]].center, coord); rays[i] = nrm4(rays[i]); }
     int count = 0;
     for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) {
         const float d = std::max(-1.0f, std::min(1.0f, dot4(rays[i], rays[j])));
@@ -715,7 +724,7 @@ void filter_images_by_angle(const Scene& s, Patch& p) {
     int n = 0;
     for (int i = 0; i < p.nimg; ++i) {
         V4 ray = sub4(s.views[p.img[i]].center, p.coord);
-        ray = div4(ray, norm4(ray));
+        ray = nrm4(ray);
         if (dot4(ray, p.normal) < s.cosAngle1) {
             if (i == 0) { p.nimg = 0; return; }
         } else p.img[n++] = p.img[i];
@@ -807,7 +816,7 @@ int refine_patch(const Scene& s, Patch& p, const uint32_t key[4], orc_counters* 
     rc.center = p.coord;
     rc.ref = p.img[0];
     rc.ray = sub4(p.coord, s.views[rc.ref].center);
-    rc.ray = div4(rc.ray, norm4(rc.ray));
+    rc.ray = nrm4(rc.ray);
     rc.dscale = p.dscale;
     rc.ascale = s.ascaleConst;
     float w[MAXI];
@@ -870,7 +879,7 @@ int is_visible(const Scene& s, const Patch& p, int image, int ix, int iy, float 
     if (dp < 0) return 1;
     const Patch& dpp = get_patch(s, dp, ctx);
     V4 ray = sub4(p.coord, vw.center);
-    ray = div4(ray, norm4(ray));
+    ray = nrm4(ray);
     const float diff = dot4(ray, sub4(p.coord, dpp.coord));
     const double factor = std::min(2.0, 2.0 + dot4(ray, p.normal));
     return diff < get_unit(s, image, p.coord) * s.cfg.csize * strict * factor ? 1 : 0;
@@ -960,7 +969,7 @@ float compute_radius(const Scene& s, const Patch& p) {
     for (int i = 0; i < p.nimg; ++i) {
         float unit = get_unit(s, p.img[i], p.coord);
         V4 ray = sub4(s.views[p.img[i]].center, p.coord);
-        ray = div4(ray, norm4(ray));
+        ray = nrm4(ray);
         const float d = dot4(ray, p.normal);
         if (0.0f < d) unit /= d; else unit = (float)(INT_MAX / 2);
         units[i] = unit;
@@ -1519,6 +1528,8 @@ void derive_thresholds(Scene& s) { /* PmMvps::init, pmmvps.cpp:32-36,54-67 */
     s.cosNeighbor120 = (float)cos(d120);
     s.sortThreshold = (float)(1.0f - cos(d10));
     s.ascaleConst = (float)(M_PI / 48.0f);
+    s.inv_sz = 1.0f / (float)(c.wsize * c.wsize);
+    s.inv_3sz = 1.0f / (float)(3 * c.wsize * c.wsize);
     s.depth = c.depth;
 }
 
@@ -1800,7 +1811,7 @@ int orc_postprocess(orc_scene* h, orc_patch* r) {
 }
 static void probe_rc(Scene& s, const Patch& p, RefineCtx& rc) {
     rc.center = p.coord; rc.ref = p.img[0];
-    rc.ray = sub4(p.coord, s.views[rc.ref].center); rc.ray = div4(rc.ray, norm4(rc.ray));
+    rc.ray = sub4(p.coord, s.views[rc.ref].center); rc.ray = nrm4(rc.ray);
     rc.dscale = p.dscale; rc.ascale = s.ascaleConst;
 }
 double orc_cost(orc_scene* h, const orc_patch* r, const float* x3) {
