@@ -34,7 +34,7 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
+    cmd = [hipcc] + FLAGS + os.environ.get("MVS_EXTRA_FLAGS", "").split() + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

@@ -1,14 +1,19 @@
 // mvs_device.cuh -- device functions of the PatchMatch-MVS engine for gfx950 (wave64).
 //
 // Execution model: ONE 64-lane wavefront works on one patch / one destination cell.  Control flow is
-// wave-uniform.  Two lane layouts coexist in registers:
+// wave-uniform.  Three lane layouts coexist in registers:
 //   * sample lanes: lane i < wsize*wsize holds sample i of the 7x7 texture window (optim.cpp:835-842);
-//     channel sums, the ssd and the NCC dot product are wave butterflies (DPP), offsets 1,2,4,8,16,32;
-//   * view lanes: lane j holds element j of a per-view array (Patch::m_images[j], its projection frame,
-//     its ray, unit, INCC ...), read back with v_readlane when a loop needs element j uniformly.
-// Arithmetic follows the conventions stated in DESIGN.md ("engine arithmetic"): fp32, no implicit
-// contraction (-ffp-contract=off), dot products as left-to-right fmaf chains, own polynomial
-// sin/cos/asin/acos/atan -- the same operation order the CPU oracle's TREE64 mode uses.
+//     channel sums, the ssd and the NCC dot product are wave butterflies (DPP + v_readlane), pairing order
+//     1,2,4,8,16,32;
+//   * view lanes: lane j holds element j of a per-view array (Patch::m_images[j], its ray, unit, INCC ...),
+//     read back with v_readlane when a loop needs element j uniformly;
+//   * frame lanes: lane 16*g + i holds the sampling frame of view i for proposal g (g < 3): the three
+//     proposals of one refinement step share one pass of decode / getPAxes / projection arithmetic.
+// Per-view scalars that need a square root or a division (msd, 1/msd, robust INCC) are gathered into view
+// lanes first, so one vector instruction sequence serves all views of an evaluation.
+// Arithmetic follows DESIGN.md "engine arithmetic": fp32, no implicit contraction (-ffp-contract=off), dot
+// products as left-to-right fmaf chains, own polynomial sin/cos/asin/acos/atan -- the same operation order
+// the CPU oracle's TREE64 mode uses, so results can be compared bit for bit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -20,6 +25,7 @@ struct F3 { float x, y, z; };
 struct F4 { float x, y, z, w; };
 
 #define DEV __device__ __forceinline__
+#define MVS_CH 5  // non-reference views processed per chunk of an evaluation (registers: 3 floats each)
 
 DEV int lane_id() { return (int)(threadIdx.x & 63u); }
 DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -35,9 +41,7 @@ DEV float norm3(F3 a) { return sqrtf(dot3(a, a)); }
 DEV F4 sub4(F4 a, F4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
 DEV F4 add4(F4 a, F4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 DEV F4 mul4(F4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
-DEV F4 div4(F4 a, float s) { return {a.x / s, a.y / s, a.z / s, a.w / s}; }
 DEV F3 sub3(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-DEV F3 div3(F3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 // v / |v| as v * (1/|v|) (Eigen 3.2 vector / scalar semantics; one IEEE division instead of three or four)
 DEV F4 nrm4(F4 a) { const float inv = 1.0f / norm4(a); return {a.x * inv, a.y * inv, a.z * inv, a.w * inv}; }
 DEV F3 nrm3(F3 a) { const float inv = 1.0f / norm3(a); return {a.x * inv, a.y * inv, a.z * inv}; }
@@ -57,9 +61,12 @@ DEV float wave_sum(float x) {
     x = x + dpp_f<0x4E>(x);   // quad_perm [2,3,0,1]   : i ^ 2
     x = x + dpp_f<0x141>(x);  // row_half_mirror       : other quad of the 8 (== i ^ 4 once quads are uniform)
     x = x + dpp_f<0x140>(x);  // row_mirror            : other half of the row of 16 (== i ^ 8)
-    // every row of 16 now holds its row sum in all lanes: i ^ 16 pairs rows (0,1) and (2,3), i ^ 32 the two halves.
-    // Four v_readlane instead of a ds_swizzle: no trip through the LDS pipeline, same additions.
-    return (rlf(x, 0) + rlf(x, 16)) + (rlf(x, 32) + rlf(x, 48));
+    // every row of 16 now holds its row sum r0..r3 in all of its lanes.  i ^ 16 pairs rows (0,1) and (2,3), i ^ 32 the
+    // halves: (r0 + r1) + (r2 + r3).  row_bcast15 into rows 1 and 3 gives r1 + r0 and r3 + r2, row_bcast31 into rows 2,3
+    // gives (r3 + r2) + (r1 + r0) in row 3 -- the same sums (fp addition commutes), 3 instructions, no LDS pipeline.
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));  // row_bcast:15 row_mask:0xa
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xc, 0xf, false));  // row_bcast:31 row_mask:0xc
+    return rlf(x, 63);
 }
 DEV float wave_min(float x) {
     x = fminf(x, dpp_f<0xB1>(x));
@@ -202,11 +209,13 @@ DEV void get_paxes(const DParams& prm, const DView* vw, F4 coord, F4 normal, F4&
 DEV float robustincc(float incc) { return incc / (1 + 3 * incc); }
 DEV float unrobustincc(float r) { return r / (1 - 3 * r); }
 
-// ------------------------------------------------------------------ texture frames (view lanes)
-// Head of Optim::getTex, optim.cpp:790-818: per view the sampling frame (top-left, dx, dy, level).
+// ------------------------------------------------------------------ texture frames (frame lanes)
+// Head of Optim::getTex, optim.cpp:790-818: per (proposal, view) the sampling frame (top-left, dx, dy), the
+// pyramid level, and the base pointer / width of that level so that the sampling loop needs no further loads.
 struct Frame {
     float tlx, tly, dxx, dxy, dyx, dyy;
-    int lvl_ok;  // level | ok << 8
+    int ok_w;            // 0 = rejected, else the width of the chosen level
+    unsigned img_lo, img_hi;  // RGBA8 pyramid level base address
 };
 DEV int level_diff(const DParams& prm, float ratio) {
     int ld = -4;
@@ -220,11 +229,10 @@ DEV int level_diff(const DParams& prm, float ratio) {
 }
 DEV float pow2_level(int ld) { return __int_as_float((127 + ld) << 23); }  // Optim::myPow2, exact powers of two
 DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, bool active) {
-    Frame f{0, 0, 0, 0, 0, 0, 0};
+    Frame f{0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!active) return f;
     const DView* vw = prm.views + v;
-    F4 ray = sub4(ld4(vw->center), coord);
-    ray = nrm4(ray);
+    F4 ray = nrm4(sub4(ld4(vw->center), coord));
     const float weight = fmaxf(0.0f, dot4(ray, pz));
     if (weight < prm.cosAngle1) return f;
     F3 center = project(vw, coord, prm.level);
@@ -232,9 +240,8 @@ DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, b
     F3 dy = sub3(project(vw, add4(coord, py), prm.level), center);
     const float ratio = (norm3(dx) + norm3(dy)) / 2.0f;
     const int ld = level_diff(prm, ratio);
-    const float scale = pow2_level(ld);
-    const int newLevel = prm.level + ld;
     const float iscale = pow2_level(-ld);  // exact reciprocal of a power of two
+    const int newLevel = prm.level + ld;
     center = scl3(center, iscale);
     dx = scl3(dx, iscale);
     dy = scl3(dy, iscale);
@@ -247,9 +254,12 @@ DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, b
     const float minx = fminf(tlx, fminf(trx, fminf(blx, brx))), maxx = fmaxf(tlx, fmaxf(trx, fmaxf(blx, brx)));
     const float miny = fminf(tly, fminf(try_, fminf(bly, bry))), maxy = fmaxf(tly, fmaxf(try_, fmaxf(bly, bry)));
     const int margin2 = 2;
-    if (minx < margin2 || vw->W[newLevel] - 1 - margin2 <= maxx || miny < margin2 || vw->H[newLevel] - 1 - margin2 <= maxy) return f;
+    const int W = vw->W[newLevel];
+    if (minx < margin2 || W - 1 - margin2 <= maxx || miny < margin2 || vw->H[newLevel] - 1 - margin2 <= maxy) return f;
     f.tlx = tlx; f.tly = tly; f.dxx = dx.x; f.dxy = dx.y; f.dyx = dy.x; f.dyy = dy.y;
-    f.lvl_ok = newLevel | (1 << 8);
+    f.ok_w = W;
+    const unsigned long long a = (unsigned long long)vw->img[newLevel];
+    f.img_lo = (unsigned)(a & 0xffffffffull); f.img_hi = (unsigned)(a >> 32);
     return f;
 }
 
@@ -263,23 +273,20 @@ struct WaveCtx {
     unsigned evals, view_evals;
 };
 
-// Tail of Optim::getTex (sampling, optim.cpp:835-842 -> Image::getColor bilinear, image.cpp:447-472)
-// followed by Optim::normalize (optim.cpp:917-940) for view-lane j of `f`.  Returns false when the view
-// was rejected.  Non-sample lanes return zeros.
-DEV bool tex_sample_norm(const DParams& prm, WaveCtx& wc, const Frame& f, int j, int vj, float& t0, float& t1, float& t2) {
-    const int lo = rli(f.lvl_ok, j);
-    if (!(lo >> 8)) return false;
-    const int level = lo & 255;
-    const float tlx = rlf(f.tlx, j), tly = rlf(f.tly, j), dxx = rlf(f.dxx, j), dxy = rlf(f.dxy, j), dyx = rlf(f.dyx, j), dyy = rlf(f.dyy, j);
-    const DView* vw = prm.views + vj;
-    const uint32_t* img = vw->img[level];
-    const int W = vw->W[level];
+// Tail of Optim::getTex (sampling, optim.cpp:835-842 -> Image::getColor bilinear, image.cpp:447-472) and the
+// first half of Optim::normalize (means and centring, optim.cpp:920-931) for frame lane e.  Returns false when
+// the view was rejected; d0..d2 = colour - mean on sample lanes (0 elsewhere), ssd = sum of squares (uniform).
+DEV bool sample_centre(const DParams& prm, WaveCtx& wc, const Frame& f, int e, float& d0, float& d1, float& d2, float& ssd) {
+    const int W = rli(f.ok_w, e);
+    if (W == 0) return false;
+    const float tlx = rlf(f.tlx, e), tly = rlf(f.tly, e), dxx = rlf(f.dxx, e), dxy = rlf(f.dxy, e), dyx = rlf(f.dyx, e), dyy = rlf(f.dyy, e);
+    const uint32_t* img = (const uint32_t*)(((unsigned long long)(unsigned)rli((int)f.img_hi, e) << 32) | (unsigned long long)(unsigned)rli((int)f.img_lo, e));
     float r = 0.0f, g = 0.0f, b = 0.0f;
     if (wc.sample_lane) {
         const float sx = fma_(dyx, wc.fy, fma_(dxx, wc.fx, tlx));
         const float sy = fma_(dyy, wc.fy, fma_(dxy, wc.fx, tly));
         const int lx = (int)sx, ly = (int)sy;
-        const uint32_t* p0 = img + (size_t)ly * W + lx;
+        const uint32_t* p0 = img + (ly * W + lx);
         const Texel2 q0 = *reinterpret_cast<const Texel2*>(p0);
         const Texel2 q1 = *reinterpret_cast<const Texel2*>(p0 + W);
         const float dx1 = sx - (float)lx, dx0 = 1.0f - dx1, dy1 = sy - (float)ly, dy0 = 1.0f - dy1;
@@ -290,18 +297,77 @@ DEV bool tex_sample_norm(const DParams& prm, WaveCtx& wc, const Frame& f, int j,
     }
     wc.view_evals++;
     const float a0 = wave_sum(r) * prm.inv_sz, a1 = wave_sum(g) * prm.inv_sz, a2 = wave_sum(b) * prm.inv_sz;
-    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+    d0 = 0.0f; d1 = 0.0f; d2 = 0.0f;
     if (wc.sample_lane) { d0 = r - a0; d1 = g - a1; d2 = b - a2; }
-    const float ssd = wave_sum(fma_(d2, d2, fma_(d1, d1, d0 * d0)));
-    float msd = sqrtf(ssd * prm.inv_3sz);
-    if (msd == 0.0f) msd = 1.0f;
-    const float inv = 1.0f / msd;
-    t0 = d0 * inv; t1 = d1 * inv; t2 = d2 * inv;
+    ssd = wave_sum(fma_(d2, d2, fma_(d1, d1, d0 * d0)));
     return true;
 }
-// Optim::dot, optim.cpp:601-609
-DEV float tex_dot(const DParams& prm, float a0, float a1, float a2, float b0, float b1, float b2) {
-    return wave_sum(fma_(a2, b2, fma_(a1, b1, a0 * b0))) * prm.inv_3sz;
+// second half of Optim::normalize, optim.cpp:932-939, on whatever lanes hold an ssd: 1 / msd
+DEV float inv_msd(const DParams& prm, float ssd) {
+    float msd = sqrtf(ssd * prm.inv_3sz);
+    if (msd == 0.0f) msd = 1.0f;
+    return 1.0f / msd;
+}
+// Optim::dot, optim.cpp:601-609, before the division by 3*sz
+DEV float tex_dot_sum(float a0, float a1, float a2, float b0, float b1, float b2) {
+    return wave_sum(fma_(a2, b2, fma_(a1, b1, a0 * b0)));
+}
+
+// Reference view against the other views of one proposal (frame lanes e0 .. e0+sz-1), in chunks of MVS_CH
+// views: sample + centre each view, then ONE sqrt/division sequence for the chunk's msd (view lanes), the
+// dot products, and ONE division sequence for the chunk's robust INCCs.
+//   MODE 0: Optim::cost_func (optim.cpp:401-468): unweighted mean of robust INCCs, double accumulator.
+//   MODE 1: Optim::computeINCC (optim.cpp:630-706): weighted (view-lane `weights`), robust or not, fp32.
+template <int MODE>
+DEV double eval_group(const DParams& prm, WaveCtx& wc, const Frame& f, int e0, int sz, int minimum, float weights, int robust) {
+    float r0, r1, r2, ssd0;
+    if (!sample_centre(prm, wc, f, e0, r0, r1, r2, ssd0)) return 2.0;
+    const float inv0 = inv_msd(prm, ssd0);
+    r0 *= inv0; r1 *= inv0; r2 *= inv0;
+    double ans = 0.0;
+    float score = 0.0f, total = 0.0f;
+    int denom = 0;
+    for (int base = 1; base < sz; base += MVS_CH) {
+        float d[MVS_CH][3];
+        float ssd_l = 1.0f;  // view lane k: ssd of chunk view k
+        unsigned okm = 0;
+#pragma unroll
+        for (int k = 0; k < MVS_CH; ++k) {
+            d[k][0] = d[k][1] = d[k][2] = 0.0f;
+            if (base + k < sz) {
+                float s;
+                if (sample_centre(prm, wc, f, e0 + base + k, d[k][0], d[k][1], d[k][2], s)) {
+                    okm |= 1u << k;
+                    if (wc.lane == k) ssd_l = s;
+                }
+            }
+        }
+        const float inv_l = inv_msd(prm, ssd_l);
+        float dot_l = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MVS_CH; ++k) {
+            if ((okm >> k) & 1u) {
+                const float inv = rlf(inv_l, k);
+                const float s = tex_dot_sum(r0, r1, r2, d[k][0] * inv, d[k][1] * inv, d[k][2] * inv);
+                if (wc.lane == k) dot_l = s;
+            }
+        }
+        const float incc_l = 1.0f - dot_l * prm.inv_3sz;  // == (float)(1.0 - (double)dot): exact in double, rounded once
+        const float val_l = (MODE == 0 || robust) ? robustincc(incc_l) : incc_l;
+#pragma unroll
+        for (int k = 0; k < MVS_CH; ++k) {
+            if ((okm >> k) & 1u) {
+                if (MODE == 0) { ans += (double)rlf(val_l, k); denom++; }
+                else { const float w = rlf(weights, base + k); total += w; score += rlf(val_l, k) * w; }
+            }
+        }
+    }
+    if (MODE == 0) {
+        if (denom < minimum - 1) return 2.0;
+        return ans / (double)denom;
+    }
+    if (total == 0.0f) return 2.0;
+    return (double)(score / total);
 }
 
 // ------------------------------------------------------------------ candidate patch (registers)
@@ -316,12 +382,11 @@ struct Cand {
 
 // Optim::computeUnits + computeWeights, optim.cpp:109-132, 942-948: returns the view-lane weight array
 DEV float compute_weights(const DParams& prm, const WaveCtx& wc, F4 coord, F4 normal, int img, int n) {
-    float unit = 0.0f;
+    float unit = 1.0f;
     if (wc.lane < n) {
         const DView* vw = prm.views + img;
         unit = get_unit(prm, vw, coord);
-        F4 ray = sub4(ld4(vw->center), coord);
-        ray = nrm4(ray);
+        const F4 ray = nrm4(sub4(ld4(vw->center), coord));
         const float d = dot4(ray, normal);
         if (0.0f < d) unit /= d; else unit = (float)(INT_MAX / 2);
     }
@@ -340,18 +405,7 @@ DEV float compute_incc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int
     const int sz = min(prm.tau, n);
     wc.evals++;
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < sz);
-    float a0, a1, a2, b0, b1, b2;
-    if (!tex_sample_norm(prm, wc, f, 0, ref, a0, a1, a2)) return 2.0f;
-    float score = 0.0f, total = 0.0f;
-    for (int i = 1; i < sz; ++i) {
-        if (!tex_sample_norm(prm, wc, f, i, rli(img, i), b0, b1, b2)) continue;
-        const float w = rlf(weights, i);
-        total += w;
-        const float incc = (float)(1.0 - (double)tex_dot(prm, a0, a1, a2, b0, b1, b2));
-        score += (robust ? robustincc(incc) : incc) * w;
-    }
-    if (total == 0.0f) return 2.0f;
-    return score / total;
+    return (float)eval_group<1>(prm, wc, f, 0, sz, 0, weights, robust);
 }
 // PatchManager::computeNcc, patch_manager.cpp:401-404
 DEV float compute_ncc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n) {
@@ -366,15 +420,46 @@ DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int im
     get_paxes(prm, prm.views + ref, coord, normal, px, py);
     wc.evals++;
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < n);
-    float a0, a1, a2, b0, b1, b2;
-    if (!tex_sample_norm(prm, wc, f, 0, ref, a0, a1, a2)) return 2.0f;
+    float r0, r1, r2, ssd0;
+    if (!sample_centre(prm, wc, f, 0, r0, r1, r2, ssd0)) return 2.0f;
+    const float inv0 = inv_msd(prm, ssd0);
+    r0 *= inv0; r1 *= inv0; r2 *= inv0;
     float incc = 2.0f;
     if (wc.lane == 0) incc = 0.0f;
-    for (int i = 1; i < n; ++i) {
-        if (!tex_sample_norm(prm, wc, f, i, rli(img, i), b0, b1, b2)) continue;
-        const float d = 1.0f - tex_dot(prm, a0, a1, a2, b0, b1, b2);
-        const float val = robust ? robustincc(d) : d;
-        if (wc.lane == i) incc = val;
+    for (int base = 1; base < n; base += MVS_CH) {
+        float d[MVS_CH][3];
+        float ssd_l = 1.0f;
+        unsigned okm = 0;
+#pragma unroll
+        for (int k = 0; k < MVS_CH; ++k) {
+            d[k][0] = d[k][1] = d[k][2] = 0.0f;
+            if (base + k < n) {
+                float s;
+                if (sample_centre(prm, wc, f, base + k, d[k][0], d[k][1], d[k][2], s)) {
+                    okm |= 1u << k;
+                    if (wc.lane == k) ssd_l = s;
+                }
+            }
+        }
+        const float inv_l = inv_msd(prm, ssd_l);
+        float dot_l = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MVS_CH; ++k) {
+            if ((okm >> k) & 1u) {
+                const float inv = rlf(inv_l, k);
+                const float s = tex_dot_sum(r0, r1, r2, d[k][0] * inv, d[k][1] * inv, d[k][2] * inv);
+                if (wc.lane == k) dot_l = s;
+            }
+        }
+        const float dd = 1.0f - dot_l * prm.inv_3sz;
+        const float val_l = robust ? robustincc(dd) : dd;
+#pragma unroll
+        for (int k = 0; k < MVS_CH; ++k) {
+            if ((okm >> k) & 1u) {
+                const float v = rlf(val_l, k);
+                if (wc.lane == base + k) incc = v;
+            }
+        }
     }
     return incc;
 }
@@ -400,8 +485,7 @@ DEV void add_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c
         const DView* vw = prm.views + wc.lane;
         const F3 ic = project(vw, c.coord, prm.level);
         if (!(ic.x < 0.0f || vw->W[prm.level] - 1 <= ic.x || ic.y < 0.0f || vw->H[prm.level] - 1 <= ic.y)) {
-            F4 ray = sub4(ld4(vw->center), c.coord);
-            ray = nrm4(ray);
+            const F4 ray = nrm4(sub4(ld4(vw->center), c.coord));
             q = prm.cosAngle0 <= dot4(ray, c.normal);
         }
     }
@@ -423,14 +507,13 @@ DEV void constraint_images(const DParams& prm, WaveCtx& wc, int* scratch, Cand& 
 }
 
 // Optim::sortImages (isFixed = 1), optim.cpp:221-258
-DEV void sort_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c) {
+DEV void sort_images(const DParams& prm, const WaveCtx& wc, Cand& c) {
     F4 ray{0, 0, 0, 0};
     float unit = 0.0f;
     bool valid = false;
     if (wc.lane < c.nimg) {  // computeUnits(patch, indexes, units, rays), optim.cpp:86-107
         const DView* vw = prm.views + c.img;
-        ray = sub4(ld4(vw->center), c.coord);
-        ray = nrm4(ray);
+        ray = nrm4(sub4(ld4(vw->center), c.coord));
         const float d = dot4(ray, c.normal);
         valid = !(d <= 0.0f);
         if (valid) unit = get_unit(prm, vw, c.coord) / d;
@@ -458,7 +541,6 @@ DEV void sort_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& 
         }
         ++k;
     }
-    (void)scratch;
     c.img = out;
     c.nimg = k;
 }
@@ -469,8 +551,7 @@ DEV void set_scales(const DParams& prm, const WaveCtx& wc, Cand& c) {
     const DView* rv = prm.views + ref;
     const float unit = get_unit(prm, rv, c.coord);
     const float unit2 = 2.0f * unit;
-    F4 ray = sub4(c.coord, ld4(rv->center));
-    ray = nrm4(ray);
+    const F4 ray = nrm4(sub4(c.coord, ld4(rv->center)));
     const int num = min(prm.tau, c.nimg);
     float dn = 0.0f;
     if (wc.lane >= 1 && wc.lane < num) {
@@ -488,10 +569,7 @@ DEV void set_scales(const DParams& prm, const WaveCtx& wc, Cand& c) {
 // PhotoSet::checkAngles, photoSet.cpp:77-103 (window test on cosines)
 DEV int check_angles(const DParams& prm, const WaveCtx& wc, const Cand& c) {
     F4 ray{0, 0, 0, 0};
-    if (wc.lane < c.nimg) {
-        ray = sub4(ld4((prm.views + c.img)->center), c.coord);
-        ray = nrm4(ray);
-    }
+    if (wc.lane < c.nimg) ray = nrm4(sub4(ld4((prm.views + c.img)->center), c.coord));
     int count = 0;
     for (int j = 1; j < c.nimg; ++j) {
         const F4 rj{rlf(ray.x, j), rlf(ray.y, j), rlf(ray.z, j), rlf(ray.w, j)};
@@ -505,7 +583,7 @@ DEV int check_angles(const DParams& prm, const WaveCtx& wc, const Cand& c) {
 DEV int pre_process(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c) {
     add_images(prm, wc, scratch, c);
     constraint_images(prm, wc, scratch, c, prm.nccThresholdBefore);
-    sort_images(prm, wc, scratch, c);
+    sort_images(prm, wc, c);
     if (c.nimg > 0) set_scales(prm, wc, c);
     if (c.nimg < prm.minImageNum) return -1;
     if (check_angles(prm, wc, c) == -1) { c.nimg = 0; return -1; }
@@ -536,11 +614,11 @@ DEV void encode(const DParams& prm, const RefineCtx& rc, F4 coord, F4 normal, fl
     x[1] = a1 / rc.ascale;
     x[2] = a2 / rc.ascale;
 }
-// Optim::decode, optim.cpp:582-599
-DEV void decode(const DParams& prm, const RefineCtx& rc, const float* x, F4& coord, F4& normal) {
-    const float t = rc.dscale * x[0];
+// Optim::decode, optim.cpp:582-599 (x0..x2 may differ per lane: frame lanes decode their own proposal)
+DEV void decode(const DParams& prm, const RefineCtx& rc, float x0, float x1, float x2, F4& coord, F4& normal) {
+    const float t = rc.dscale * x0;
     coord = {fma_(t, rc.ray.x, rc.center.x), fma_(t, rc.ray.y, rc.center.y), fma_(t, rc.ray.z, rc.center.z), fma_(t, rc.ray.w, rc.center.w)};
-    const float angle1 = x[1] * rc.ascale, angle2 = x[2] * rc.ascale;
+    const float angle1 = x1 * rc.ascale, angle2 = x2 * rc.ascale;
     const float s1 = pm_sinf(angle1), c1 = pm_cosf(angle1), s2 = pm_sinf(angle2), c2 = pm_cosf(angle2);
     const float fx = s1 * c2, fy = s2, fz = -c1 * c2;
     const DView* vw = prm.views + rc.ref;
@@ -548,63 +626,67 @@ DEV void decode(const DParams& prm, const RefineCtx& rc, const float* x, F4& coo
               fma_(vw->zaxis[1], fz, fma_(vw->yaxis[1], fy, vw->xaxis[1] * fx)),
               fma_(vw->zaxis[2], fz, fma_(vw->yaxis[2], fy, vw->xaxis[2] * fx)), 0.0f};
 }
-// Optim::cost_func, optim.cpp:401-468
-DEV double cost_func(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int img, int n, const float* x) {
+// Optim::cost_func (optim.cpp:401-468) for up to three proposals at once: lane 16*g + i decodes proposal g
+// (x0..x2 hold that lane's proposal), builds the patch axes and the frame of view i; then each proposal is
+// evaluated in turn.  imgx = m_images replicated into every group of 16 lanes.
+DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int imgx, int n, bool three, float x0, float x1, float x2,
+                    double& f0, double& f1, double& f2) {
     F4 coord, normal, px, py;
-    decode(prm, rc, x, coord, normal);
+    decode(prm, rc, x0, x1, x2, coord, normal);
     get_paxes(prm, prm.views + rc.ref, coord, normal, px, py);
     const int sz = min(prm.tau, n);
     const int minimum = min(prm.minImageNum, sz);
+    const int g = wc.lane >> 4, i = wc.lane & 15;
+    const Frame f = make_frame(prm, coord, px, py, normal, imgx, g < (three ? 3 : 1) && i < sz);
     wc.evals++;
-    const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < sz);
-    float a0, a1, a2, b0, b1, b2;
-    if (!tex_sample_norm(prm, wc, f, 0, rc.ref, a0, a1, a2)) return 2.0;
-    double ans = 0.0;
-    int denom = 0;
-    for (int i = 1; i < sz; ++i) {
-        if (!tex_sample_norm(prm, wc, f, i, rli(img, i), b0, b1, b2)) continue;
-        ans += (double)robustincc((float)(1.0 - (double)tex_dot(prm, a0, a1, a2, b0, b1, b2)));
-        denom++;
+    f0 = eval_group<0>(prm, wc, f, 0, sz, minimum, 0.0f, 1);
+    f1 = f2 = 2.0;
+    if (three) {
+        wc.evals += 2;
+        f1 = eval_group<0>(prm, wc, f, 16, sz, minimum, 0.0f, 1);
+        f2 = eval_group<0>(prm, wc, f, 32, sz, minimum, 0.0f, 1);
     }
-    if (denom < minimum - 1) return 2.0;
-    return ans / (double)denom;
 }
 // Optim::refinePatch, optim.cpp:480-547, BOBYQA replaced by the halving random search
 DEV void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
     RefineCtx rc;
     rc.center = c.coord;
     rc.ref = rli(c.img, 0);
-    rc.ray = sub4(c.coord, ld4((prm.views + rc.ref)->center));
-    rc.ray = nrm4(rc.ray);
+    rc.ray = nrm4(sub4(c.coord, ld4((prm.views + rc.ref)->center)));
     rc.dscale = c.dscale;
     rc.ascale = prm.ascaleConst;
     const float w = compute_weights(prm, wc, c.coord, c.normal, c.img, c.nimg);
+    const int imgx = __shfl(c.img, wc.lane & 15);
     float x[3];
     encode(prm, rc, c.coord, c.normal, x);
     const float amin = -23.99999f, amax = 23.99999f;
     x[1] = fmaxf(fminf(x[1], amax), amin);
     x[2] = fmaxf(fminf(x[2], amax), amin);
-    double fbest = cost_func(prm, wc, rc, c.img, c.nimg, x);
+    float bx0 = x[0], bx1 = x[1], bx2 = x[2];
+    double f0, f1, f2;
+    cost_func3(prm, wc, rc, imgx, c.nimg, false, bx0, bx1, bx2, f0, f1, f2);
+    double fbest = f0;
     float rd = prm.rd0, ra = prm.ra0;
+    const int g = wc.lane >> 4;  // this lane's proposal: 0 depth only, 1 angles only, 2 both (3: idle, computes proposal 2 again)
+    const uint32_t gj = (uint32_t)min(g, 2);
     for (int k = 0; k < prm.refine_steps; ++k) {
-        float bx0 = x[0], bx1 = x[1], bx2 = x[2];
-        double fstep = 0.0;
-        for (int j = 0; j < 3; ++j) {
-            const uint32_t draw = 16u + (uint32_t)(k * 3 + j) * 3u;
-            const float u0 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 0);
-            const float u1 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 1);
-            const float u2 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 2);
-            float cx[3];
-            cx[0] = (j == 1) ? x[0] : fma_(u0, rd, x[0]);
-            cx[1] = (j == 0) ? x[1] : fmaxf(fminf(fma_(u1, ra, x[1]), amax), amin);
-            cx[2] = (j == 0) ? x[2] : fmaxf(fminf(fma_(u2, ra, x[2]), amax), amin);
-            const double fj = cost_func(prm, wc, rc, c.img, c.nimg, cx);
-            if (j == 0 || fj < fstep) { fstep = fj; bx0 = cx[0]; bx1 = cx[1]; bx2 = cx[2]; }
-        }
-        if (fstep < fbest) { fbest = fstep; x[0] = bx0; x[1] = bx1; x[2] = bx2; }
+        const uint32_t draw = 16u + ((uint32_t)(k * 3) + gj) * 3u;
+        const float u0 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 0);
+        const float u1 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 1);
+        const float u2 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 2);
+        const float cx0 = (gj == 1u) ? bx0 : fma_(u0, rd, bx0);
+        const float cx1 = (gj == 0u) ? bx1 : fmaxf(fminf(fma_(u1, ra, bx1), amax), amin);
+        const float cx2 = (gj == 0u) ? bx2 : fmaxf(fminf(fma_(u2, ra, bx2), amax), amin);
+        cost_func3(prm, wc, rc, imgx, c.nimg, true, cx0, cx1, cx2, f0, f1, f2);
+        int jb = 0;
+        double fstep = f0;
+        if (f1 < fstep) { fstep = f1; jb = 1; }
+        if (f2 < fstep) { fstep = f2; jb = 2; }
+        if (fstep < fbest) { fbest = fstep; bx0 = rlf(cx0, 16 * jb); bx1 = rlf(cx1, 16 * jb); bx2 = rlf(cx2, 16 * jb); }
         rd *= 0.5f; ra *= 0.5f;
     }
-    decode(prm, rc, x, c.coord, c.normal);
+    x[0] = bx0; x[1] = bx1; x[2] = bx2;
+    decode(prm, rc, x[0], x[1], x[2], c.coord, c.normal);
     c.normal.w = 0.0f;
     c.ncc = 1.0f - unrobustincc(compute_incc(prm, wc, c.coord, c.normal, c.img, c.nimg, w, 1));
 }
@@ -614,8 +696,7 @@ DEV void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, uin
 DEV void filter_images_by_angle(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c) {
     bool bad = false;
     if (wc.lane < c.nimg) {
-        F4 ray = sub4(ld4((prm.views + c.img)->center), c.coord);
-        ray = nrm4(ray);
+        const F4 ray = nrm4(sub4(ld4((prm.views + c.img)->center), c.coord));
         bad = dot4(ray, c.normal) < prm.cosAngle1;
     }
     const unsigned long long bm = ballot(bad);
@@ -638,10 +719,13 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     const Frame f = make_frame(prm, c.coord, px, py, c.normal, c.img, wc.lane < n);
     unsigned okmask = 0;
     __syncthreads();
+    // centred textures to LDS, their ssd to view lanes; then one sqrt/division sequence for all views
+    float ssd_l = 1.0f;
     for (int i = 0; i < n; ++i) {
-        float t0, t1, t2;
-        if (tex_sample_norm(prm, wc, f, i, rli(c.img, i), t0, t1, t2)) {
+        float t0, t1, t2, s;
+        if (sample_centre(prm, wc, f, i, t0, t1, t2, s)) {
             okmask |= 1u << i;
+            if (wc.lane == i) ssd_l = s;
             if (wc.sample_lane) {
                 texs[(i * 3 + 0) * tstride + wc.lane] = t0;
                 texs[(i * 3 + 1) * tstride + wc.lane] = t1;
@@ -649,24 +733,35 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
             }
         }
     }
+    const float inv_l = inv_msd(prm, ssd_l);
     __syncthreads();
     float acc = 0.0f;  // view lane i: sum_j inccs[i][j], j ascending
     for (int a = 0; a < n; ++a) {
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
         const bool oka = (okmask >> a) & 1u;
         if (oka && wc.sample_lane) {
-            a0 = texs[(a * 3 + 0) * tstride + wc.lane]; a1 = texs[(a * 3 + 1) * tstride + wc.lane]; a2 = texs[(a * 3 + 2) * tstride + wc.lane];
+            const float inv = rlf(inv_l, a);
+            a0 = texs[(a * 3 + 0) * tstride + wc.lane] * inv; a1 = texs[(a * 3 + 1) * tstride + wc.lane] * inv; a2 = texs[(a * 3 + 2) * tstride + wc.lane] * inv;
         }
+        float dot_l = 0.0f;  // view lane b: sum of products of (a, b)
         for (int b = a + 1; b < n; ++b) {
-            float val = 2.0f;
             if (oka && ((okmask >> b) & 1u)) {
                 float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
                 if (wc.sample_lane) {
-                    b0 = texs[(b * 3 + 0) * tstride + wc.lane]; b1 = texs[(b * 3 + 1) * tstride + wc.lane]; b2 = texs[(b * 3 + 2) * tstride + wc.lane];
+                    const float inv = rlf(inv_l, b);
+                    b0 = texs[(b * 3 + 0) * tstride + wc.lane] * inv; b1 = texs[(b * 3 + 1) * tstride + wc.lane] * inv; b2 = texs[(b * 3 + 2) * tstride + wc.lane] * inv;
                 }
-                val = robustincc(1.0f - tex_dot(prm, a0, a1, a2, b0, b1, b2));
+                const float s = tex_dot_sum(a0, a1, a2, b0, b1, b2);
+                if (wc.lane == b) dot_l = s;
             }
-            if (wc.lane == a || wc.lane == b) acc += val;
+        }
+        // view lane b > a: inccs[a][b] (2.0 when either texture is missing)
+        float val_l = robustincc(1.0f - dot_l * prm.inv_3sz);
+        if (!(oka && wc.lane < MVS_LISTCAP && ((okmask >> (wc.lane & 31)) & 1u))) val_l = 2.0f;
+        if (wc.lane > a && wc.lane < n) acc += val_l;
+        for (int b = a + 1; b < n; ++b) {
+            const float v = rlf(val_l, b);
+            if (wc.lane == a) acc += v;
         }
     }
     const float big = (float)(INT_MAX / 2);
@@ -689,8 +784,7 @@ DEV int is_visible(const DParams& prm, const Cand& c, int image, int ix, int iy,
     if (dp == ~0ull) return 1;
     const DPatch* q = prm.pool + (uint32_t)(dp & 0xffffffffull);
     const F4 qc = ld4(q->coord);
-    F4 ray = sub4(c.coord, ld4(vw->center));
-    ray = nrm4(ray);
+    const F4 ray = nrm4(sub4(c.coord, ld4(vw->center)));
     const float diff = dot4(ray, sub4(c.coord, qc));
     const double factor = fmin(2.0, 2.0 + (double)dot4(ray, c.normal));
     const float lhs = get_unit(prm, vw, c.coord) * (float)prm.csize * strict;

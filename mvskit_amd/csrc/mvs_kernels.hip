@@ -251,7 +251,10 @@ __global__ __launch_bounds__(64) void k_fill_ncc(DParams prm, unsigned long long
 // raster sweep would reach them, and runs Propagate::propagatePatch (propagate.cpp:126-218) on its own list.
 DEV bool rank_before(float na, int a, float nb, int b) { return (na != nb) ? (na > nb) : (a < b); }
 
-__global__ __launch_bounds__(64) void k_sweep(DParams prm, SweepArgs a) {
+#ifndef MVS_SWEEP_WAVES
+#define MVS_SWEEP_WAVES 3  // waves per SIMD the register allocator is asked to fit (k_sweep)
+#endif
+__global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, SweepArgs a) {
     __shared__ int s_scratch[192];
     extern __shared__ float s_texs[];
     // XCD-aware job order: blocks are dealt round-robin over the 8 XCDs, so block b works on job
@@ -313,8 +316,6 @@ __global__ __launch_bounds__(64) void k_sweep(DParams prm, SweepArgs a) {
             if (!(sp->flags & 1)) continue;
             const int n = nalive++;
             if (sp->images[0] != v) continue;
-            Cand src;
-            load_cand(sp, wc, src);
             const int srcslot = sidx * prm.cap + n;
             // ---- Propagate::propagatePatch, propagate.cpp:153-213
             for (int it = 0; it < prm.max_propag; ++it) {
@@ -334,7 +335,11 @@ __global__ __launch_bounds__(64) void k_sweep(DParams prm, SweepArgs a) {
                     const DPatch* wp = worst >= MVS_NEWBASE ? a.staging + (worst - MVS_NEWBASE) : prm.pool + worst;
                     ic = project(vw, ld4(wp->coord), prm.level);
                 }
-                if (!generate_patch(prm, wc, s_scratch, src, ic, c)) continue;
+                {
+                    Cand src;  // loaded per trial: its registers are free again during the refinement
+                    load_cand(sp, wc, src);
+                    if (!generate_patch(prm, wc, s_scratch, src, ic, c)) continue;
+                }
                 ++n_cand;
                 if (np >= prm.cap && c.ncc < worst_ncc) { ++n_pref; continue; }
                 ++n_patch;
@@ -496,7 +501,8 @@ __global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, co
         rc.dscale = c.dscale; rc.ascale = prm.ascaleConst;
         float x[3];
         encode(prm, rc, c.coord, c.normal, x);
-        const double f = cost_func(prm, wc, rc, c.img, c.nimg, x);
+        double f, fu1, fu2;
+        cost_func3(prm, wc, rc, __shfl(c.img, wc.lane & 15), c.nimg, false, x[0], x[1], x[2], f, fu1, fu2);
         if (wc.lane == 0) out_f[i] = (float)f;
     }
 }
