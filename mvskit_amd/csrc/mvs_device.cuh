@@ -212,9 +212,12 @@ DEV float unrobustincc(float r) { return r / (1 - 3 * r); }
 // ------------------------------------------------------------------ texture frames (frame lanes)
 // Head of Optim::getTex, optim.cpp:790-818: per (proposal, view) the sampling frame (top-left, dx, dy), the
 // pyramid level, and the base pointer / width of that level so that the sampling loop needs no further loads.
+// A rejected view keeps ok = 0 and a harmless frame (the 2x2 texels at the origin of the view's own image), so
+// that sampling can stay branch-free; its results are masked out by the caller.
 struct Frame {
     float tlx, tly, dxx, dxy, dyx, dyy;
-    int ok_w;            // 0 = rejected, else the width of the chosen level
+    int w;               // width of the chosen level
+    int ok;              // 1 = the view passed the angle gate and getTexSafe
     unsigned img_lo, img_hi;  // RGBA8 pyramid level base address
 };
 DEV int level_diff(const DParams& prm, float ratio) {
@@ -229,10 +232,15 @@ DEV int level_diff(const DParams& prm, float ratio) {
 }
 DEV float pow2_level(int ld) { return __int_as_float((127 + ld) << 23); }  // Optim::myPow2, exact powers of two
 DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, bool active) {
-    Frame f{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Frame f{0, 0, 0, 0, 0, 0, 4, 0, 0, 0};
     if (!active) return f;
     const DView* vw = prm.views + v;
-    F4 ray = nrm4(sub4(ld4(vw->center), coord));
+    {
+        const unsigned long long a = (unsigned long long)vw->img[prm.level];
+        f.img_lo = (unsigned)(a & 0xffffffffull); f.img_hi = (unsigned)(a >> 32);
+        f.w = vw->W[prm.level];
+    }
+    const F4 ray = nrm4(sub4(ld4(vw->center), coord));
     const float weight = fmaxf(0.0f, dot4(ray, pz));
     if (weight < prm.cosAngle1) return f;
     F3 center = project(vw, coord, prm.level);
@@ -257,7 +265,7 @@ DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, b
     const int W = vw->W[newLevel];
     if (minx < margin2 || W - 1 - margin2 <= maxx || miny < margin2 || vw->H[newLevel] - 1 - margin2 <= maxy) return f;
     f.tlx = tlx; f.tly = tly; f.dxx = dx.x; f.dxy = dx.y; f.dyx = dy.x; f.dyy = dy.y;
-    f.ok_w = W;
+    f.w = W; f.ok = 1;
     const unsigned long long a = (unsigned long long)vw->img[newLevel];
     f.img_lo = (unsigned)(a & 0xffffffffull); f.img_hi = (unsigned)(a >> 32);
     return f;
@@ -273,34 +281,50 @@ struct WaveCtx {
     unsigned evals, view_evals;
 };
 
-// Tail of Optim::getTex (sampling, optim.cpp:835-842 -> Image::getColor bilinear, image.cpp:447-472) and the
-// first half of Optim::normalize (means and centring, optim.cpp:920-931) for frame lane e.  Returns false when
-// the view was rejected; d0..d2 = colour - mean on sample lanes (0 elsewhere), ssd = sum of squares (uniform).
-DEV bool sample_centre(const DParams& prm, WaveCtx& wc, const Frame& f, int e, float& d0, float& d1, float& d2, float& ssd) {
-    const int W = rli(f.ok_w, e);
-    if (W == 0) return false;
+// Tail of Optim::getTex (sampling, optim.cpp:835-842 -> Image::getColor bilinear, image.cpp:447-472) and
+// Optim::normalize (optim.cpp:917-940) for frame lane e, split in two so that the loads of the next views are in
+// flight while the current ones are reduced, and branch-free so that the independent chains of the three proposals
+// of a refinement step interleave:
+//   tex_issue  : frame -> sample position -> the two 8-byte texel loads (nothing waits on them here)
+//   tex_centre : bilinear blend, channel means, centring
+struct Pending {
+    int ok;
+    Texel2 q0, q1;
+    float dx1, dy1;
+};
+DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int e) {
+    Pending p;
+    p.ok = rli(f.ok, e);
+    const int W = rli(f.w, e);
     const float tlx = rlf(f.tlx, e), tly = rlf(f.tly, e), dxx = rlf(f.dxx, e), dxy = rlf(f.dxy, e), dyx = rlf(f.dyx, e), dyy = rlf(f.dyy, e);
     const uint32_t* img = (const uint32_t*)(((unsigned long long)(unsigned)rli((int)f.img_hi, e) << 32) | (unsigned long long)(unsigned)rli((int)f.img_lo, e));
-    float r = 0.0f, g = 0.0f, b = 0.0f;
-    if (wc.sample_lane) {
-        const float sx = fma_(dyx, wc.fy, fma_(dxx, wc.fx, tlx));
-        const float sy = fma_(dyy, wc.fy, fma_(dxy, wc.fx, tly));
-        const int lx = (int)sx, ly = (int)sy;
-        const uint32_t* p0 = img + (ly * W + lx);
-        const Texel2 q0 = *reinterpret_cast<const Texel2*>(p0);
-        const Texel2 q1 = *reinterpret_cast<const Texel2*>(p0 + W);
-        const float dx1 = sx - (float)lx, dx0 = 1.0f - dx1, dy1 = sy - (float)ly, dy0 = 1.0f - dy1;
-        const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
-        r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
-        g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
-        b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
-    }
-    wc.view_evals++;
+    const float sx = wc.sample_lane ? fma_(dyx, wc.fy, fma_(dxx, wc.fx, tlx)) : 0.0f;
+    const float sy = wc.sample_lane ? fma_(dyy, wc.fy, fma_(dxy, wc.fx, tly)) : 0.0f;
+    const int lx = (int)sx, ly = (int)sy;
+    const uint32_t* p0 = img + (ly * W + lx);
+    p.q0 = *reinterpret_cast<const Texel2*>(p0);
+    p.q1 = *reinterpret_cast<const Texel2*>(p0 + W);
+    p.dx1 = sx - (float)lx; p.dy1 = sy - (float)ly;
+    return p;
+}
+// colour - mean on sample lanes (0 elsewhere)
+DEV void tex_centre(const DParams& prm, const WaveCtx& wc, const Pending& p, float& d0, float& d1, float& d2) {
+    const Texel2 q0 = p.q0, q1 = p.q1;
+    const float dx1 = p.dx1, dx0 = 1.0f - dx1, dy1 = p.dy1, dy0 = 1.0f - dy1;
+    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+    float r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
+    float g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
+    float b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
+    if (!wc.sample_lane) { r = 0.0f; g = 0.0f; b = 0.0f; }
     const float a0 = wave_sum(r) * prm.inv_sz, a1 = wave_sum(g) * prm.inv_sz, a2 = wave_sum(b) * prm.inv_sz;
-    d0 = 0.0f; d1 = 0.0f; d2 = 0.0f;
-    if (wc.sample_lane) { d0 = r - a0; d1 = g - a1; d2 = b - a2; }
-    ssd = wave_sum(fma_(d2, d2, fma_(d1, d1, d0 * d0)));
-    return true;
+    d0 = wc.sample_lane ? r - a0 : 0.0f;
+    d1 = wc.sample_lane ? g - a1 : 0.0f;
+    d2 = wc.sample_lane ? b - a2 : 0.0f;
+}
+DEV float ssd_sum(float d0, float d1, float d2) { return wave_sum(fma_(d2, d2, fma_(d1, d1, d0 * d0))); }
+// Optim::dot, optim.cpp:601-609, on centred textures, before the scale factors
+DEV float tex_dot_sum(float a0, float a1, float a2, float b0, float b1, float b2) {
+    return wave_sum(fma_(a2, b2, fma_(a1, b1, a0 * b0)));
 }
 // second half of Optim::normalize, optim.cpp:932-939, on whatever lanes hold an ssd: 1 / msd
 DEV float inv_msd(const DParams& prm, float ssd) {
@@ -308,66 +332,64 @@ DEV float inv_msd(const DParams& prm, float ssd) {
     if (msd == 0.0f) msd = 1.0f;
     return 1.0f / msd;
 }
-// Optim::dot, optim.cpp:601-609, before the division by 3*sz
-DEV float tex_dot_sum(float a0, float a1, float a2, float b0, float b1, float b2) {
-    return wave_sum(fma_(a2, b2, fma_(a1, b1, a0 * b0)));
-}
 
-// Reference view against the other views of one proposal (frame lanes e0 .. e0+sz-1), in chunks of MVS_CH
-// views: sample + centre each view, then ONE sqrt/division sequence for the chunk's msd (view lanes), the
-// dot products, and ONE division sequence for the chunk's robust INCCs.
-//   MODE 0: Optim::cost_func (optim.cpp:401-468): unweighted mean of robust INCCs, double accumulator.
-//   MODE 1: Optim::computeINCC (optim.cpp:630-706): weighted (view-lane `weights`), robust or not, fp32.
-template <int MODE>
-DEV double eval_group(const DParams& prm, WaveCtx& wc, const Frame& f, int e0, int sz, int minimum, float weights, int robust) {
-    float r0, r1, r2, ssd0;
-    if (!sample_centre(prm, wc, f, e0, r0, r1, r2, ssd0)) return 2.0;
-    const float inv0 = inv_msd(prm, ssd0);
-    r0 *= inv0; r1 *= inv0; r2 *= inv0;
-    double ans = 0.0;
-    float score = 0.0f, total = 0.0f;
-    int denom = 0;
-    for (int base = 1; base < sz; base += MVS_CH) {
-        float d[MVS_CH][3];
-        float ssd_l = 1.0f;  // view lane k: ssd of chunk view k
-        unsigned okm = 0;
+// Core of every texture evaluation: NP proposals (frame lanes 16*g + k, k < n) against their reference view k = 0.
+// Leaves in frame lane 16*g + k (k >= 1) the INCC of view k against the reference of proposal g,
+//     1 - (sum(d0*dk) * (inv0 * invk)) / (3*sz)              (Optim::dot on normalised textures, optim.cpp:601-609)
+// and in okm[g] the bit mask of views that were sampled.  One sqrt/division sequence serves all NP*n views.
+template <int NP>
+DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[NP], float& incc_l) {
+    float d0[NP][3];
+    float ssd_l = 1.0f, dot_l = 0.0f;
+    Pending pn[NP];
 #pragma unroll
-        for (int k = 0; k < MVS_CH; ++k) {
-            d[k][0] = d[k][1] = d[k][2] = 0.0f;
-            if (base + k < sz) {
-                float s;
-                if (sample_centre(prm, wc, f, e0 + base + k, d[k][0], d[k][1], d[k][2], s)) {
-                    okm |= 1u << k;
-                    if (wc.lane == k) ssd_l = s;
-                }
-            }
+    for (int g = 0; g < NP; ++g) { okm[g] = 0u; pn[g] = tex_issue(prm, wc, f, 16 * g); }
+    {
+        Pending p[NP];
+#pragma unroll
+        for (int g = 0; g < NP; ++g) p[g] = pn[g];
+        if (n > 1) {
+#pragma unroll
+            for (int g = 0; g < NP; ++g) pn[g] = tex_issue(prm, wc, f, 16 * g + 1);
         }
-        const float inv_l = inv_msd(prm, ssd_l);
-        float dot_l = 0.0f;
 #pragma unroll
-        for (int k = 0; k < MVS_CH; ++k) {
-            if ((okm >> k) & 1u) {
-                const float inv = rlf(inv_l, k);
-                const float s = tex_dot_sum(r0, r1, r2, d[k][0] * inv, d[k][1] * inv, d[k][2] * inv);
-                if (wc.lane == k) dot_l = s;
-            }
-        }
-        const float incc_l = 1.0f - dot_l * prm.inv_3sz;  // == (float)(1.0 - (double)dot): exact in double, rounded once
-        const float val_l = (MODE == 0 || robust) ? robustincc(incc_l) : incc_l;
-#pragma unroll
-        for (int k = 0; k < MVS_CH; ++k) {
-            if ((okm >> k) & 1u) {
-                if (MODE == 0) { ans += (double)rlf(val_l, k); denom++; }
-                else { const float w = rlf(weights, base + k); total += w; score += rlf(val_l, k) * w; }
-            }
+        for (int g = 0; g < NP; ++g) {
+            tex_centre(prm, wc, p[g], d0[g][0], d0[g][1], d0[g][2]);
+            const float s = ssd_sum(d0[g][0], d0[g][1], d0[g][2]);
+            okm[g] |= (unsigned)p[g].ok;
+            if (wc.lane == 16 * g) ssd_l = s;
         }
     }
-    if (MODE == 0) {
-        if (denom < minimum - 1) return 2.0;
-        return ans / (double)denom;
+    for (int k = 1; k < n; ++k) {
+        Pending p[NP];
+#pragma unroll
+        for (int g = 0; g < NP; ++g) p[g] = pn[g];
+        if (k + 1 < n) {
+#pragma unroll
+            for (int g = 0; g < NP; ++g) pn[g] = tex_issue(prm, wc, f, 16 * g + k + 1);
+        }
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            float e0, e1, e2;
+            tex_centre(prm, wc, p[g], e0, e1, e2);
+            const float s = ssd_sum(e0, e1, e2);
+            const float dt = tex_dot_sum(d0[g][0], d0[g][1], d0[g][2], e0, e1, e2);
+            okm[g] |= (unsigned)p[g].ok << k;
+            if (wc.lane == 16 * g + k) { ssd_l = s; dot_l = dt; }
+        }
     }
-    if (total == 0.0f) return 2.0;
-    return (double)(score / total);
+    // the metric's work count: views that sampled; nothing counts when the reference view itself was rejected
+    // (Optim::cost_func / computeINCC / setINCCs return before looking at the others, optim.cpp:448,657,725)
+#pragma unroll
+    for (int g = 0; g < NP; ++g) wc.view_evals += (okm[g] & 1u) ? (unsigned)__popc(okm[g]) : 0u;
+    const float inv_l = inv_msd(prm, ssd_l);
+    float inv0_l = rlf(inv_l, 0);
+    if (NP > 1) {
+        const int g = wc.lane >> 4;
+        const float i1 = rlf(inv_l, 16), i2 = rlf(inv_l, 32);
+        inv0_l = g == 1 ? i1 : (g == 2 ? i2 : inv0_l);
+    }
+    incc_l = 1.0f - (dot_l * (inv0_l * inv_l)) * prm.inv_3sz;
 }
 
 // ------------------------------------------------------------------ candidate patch (registers)
@@ -405,7 +427,20 @@ DEV float compute_incc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int
     const int sz = min(prm.tau, n);
     wc.evals++;
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < sz);
-    return (float)eval_group<1>(prm, wc, f, 0, sz, 0, weights, robust);
+    unsigned okm[1];
+    float incc_l;
+    eval_core<1>(prm, wc, f, sz, okm, incc_l);
+    if (!(okm[0] & 1u)) return 2.0f;
+    const float val_l = robust ? robustincc(incc_l) : incc_l;
+    float score = 0.0f, total = 0.0f;
+    for (int i = 1; i < sz; ++i) {
+        if (!((okm[0] >> i) & 1u)) continue;
+        const float w = rlf(weights, i);
+        total += w;
+        score += rlf(val_l, i) * w;
+    }
+    if (total == 0.0f) return 2.0f;
+    return score / total;
 }
 // PatchManager::computeNcc, patch_manager.cpp:401-404
 DEV float compute_ncc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n) {
@@ -420,47 +455,13 @@ DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int im
     get_paxes(prm, prm.views + ref, coord, normal, px, py);
     wc.evals++;
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < n);
-    float r0, r1, r2, ssd0;
-    if (!sample_centre(prm, wc, f, 0, r0, r1, r2, ssd0)) return 2.0f;
-    const float inv0 = inv_msd(prm, ssd0);
-    r0 *= inv0; r1 *= inv0; r2 *= inv0;
-    float incc = 2.0f;
+    unsigned okm[1];
+    float incc_l;
+    eval_core<1>(prm, wc, f, n, okm, incc_l);
+    if (!(okm[0] & 1u)) return 2.0f;
+    float incc = robust ? robustincc(incc_l) : incc_l;
+    if (wc.lane >= MVS_LISTCAP || !((okm[0] >> (wc.lane & 31)) & 1u)) incc = 2.0f;
     if (wc.lane == 0) incc = 0.0f;
-    for (int base = 1; base < n; base += MVS_CH) {
-        float d[MVS_CH][3];
-        float ssd_l = 1.0f;
-        unsigned okm = 0;
-#pragma unroll
-        for (int k = 0; k < MVS_CH; ++k) {
-            d[k][0] = d[k][1] = d[k][2] = 0.0f;
-            if (base + k < n) {
-                float s;
-                if (sample_centre(prm, wc, f, base + k, d[k][0], d[k][1], d[k][2], s)) {
-                    okm |= 1u << k;
-                    if (wc.lane == k) ssd_l = s;
-                }
-            }
-        }
-        const float inv_l = inv_msd(prm, ssd_l);
-        float dot_l = 0.0f;
-#pragma unroll
-        for (int k = 0; k < MVS_CH; ++k) {
-            if ((okm >> k) & 1u) {
-                const float inv = rlf(inv_l, k);
-                const float s = tex_dot_sum(r0, r1, r2, d[k][0] * inv, d[k][1] * inv, d[k][2] * inv);
-                if (wc.lane == k) dot_l = s;
-            }
-        }
-        const float dd = 1.0f - dot_l * prm.inv_3sz;
-        const float val_l = robust ? robustincc(dd) : dd;
-#pragma unroll
-        for (int k = 0; k < MVS_CH; ++k) {
-            if ((okm >> k) & 1u) {
-                const float v = rlf(val_l, k);
-                if (wc.lane == base + k) incc = v;
-            }
-        }
-    }
     return incc;
 }
 
@@ -629,6 +630,18 @@ DEV void decode(const DParams& prm, const RefineCtx& rc, float x0, float x1, flo
 // Optim::cost_func (optim.cpp:401-468) for up to three proposals at once: lane 16*g + i decodes proposal g
 // (x0..x2 hold that lane's proposal), builds the patch axes and the frame of view i; then each proposal is
 // evaluated in turn.  imgx = m_images replicated into every group of 16 lanes.
+DEV double cost_of_group(const DParams& prm, const WaveCtx& wc, unsigned okm, float val_l, int g, int sz, int minimum) {
+    if (!(okm & 1u)) return 2.0;
+    double ans = 0.0;
+    int denom = 0;
+    for (int i = 1; i < sz; ++i) {
+        if (!((okm >> i) & 1u)) continue;
+        ans += (double)rlf(val_l, 16 * g + i);
+        denom++;
+    }
+    if (denom < minimum - 1) return 2.0;
+    return ans / (double)denom;
+}
 DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int imgx, int n, bool three, float x0, float x1, float x2,
                     double& f0, double& f1, double& f2) {
     F4 coord, normal, px, py;
@@ -638,13 +651,22 @@ DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
     const int minimum = min(prm.minImageNum, sz);
     const int g = wc.lane >> 4, i = wc.lane & 15;
     const Frame f = make_frame(prm, coord, px, py, normal, imgx, g < (three ? 3 : 1) && i < sz);
-    wc.evals++;
-    f0 = eval_group<0>(prm, wc, f, 0, sz, minimum, 0.0f, 1);
+    float incc_l;
     f1 = f2 = 2.0;
     if (three) {
-        wc.evals += 2;
-        f1 = eval_group<0>(prm, wc, f, 16, sz, minimum, 0.0f, 1);
-        f2 = eval_group<0>(prm, wc, f, 32, sz, minimum, 0.0f, 1);
+        wc.evals += 3;
+        unsigned okm[3];
+        eval_core<3>(prm, wc, f, sz, okm, incc_l);
+        const float val_l = robustincc(incc_l);
+        f0 = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
+        f1 = cost_of_group(prm, wc, okm[1], val_l, 1, sz, minimum);
+        f2 = cost_of_group(prm, wc, okm[2], val_l, 2, sz, minimum);
+    } else {
+        wc.evals += 1;
+        unsigned okm[1];
+        eval_core<1>(prm, wc, f, sz, okm, incc_l);
+        const float val_l = robustincc(incc_l);
+        f0 = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
     }
 }
 // Optim::refinePatch, optim.cpp:480-547, BOBYQA replaced by the halving random search
@@ -721,10 +743,16 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     __syncthreads();
     // centred textures to LDS, their ssd to view lanes; then one sqrt/division sequence for all views
     float ssd_l = 1.0f;
-    for (int i = 0; i < n; ++i) {
-        float t0, t1, t2, s;
-        if (sample_centre(prm, wc, f, i, t0, t1, t2, s)) {
-            okmask |= 1u << i;
+    {
+        Pending pn = tex_issue(prm, wc, f, 0);
+        for (int i = 0; i < n; ++i) {
+            const Pending p = pn;
+            if (i + 1 < n) pn = tex_issue(prm, wc, f, i + 1);
+            float t0, t1, t2;
+            tex_centre(prm, wc, p, t0, t1, t2);
+            const float s = ssd_sum(t0, t1, t2);
+            okmask |= (unsigned)p.ok << i;
+            wc.view_evals += (unsigned)p.ok;
             if (wc.lane == i) ssd_l = s;
             if (wc.sample_lane) {
                 texs[(i * 3 + 0) * tstride + wc.lane] = t0;
@@ -740,23 +768,22 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
         const bool oka = (okmask >> a) & 1u;
         if (oka && wc.sample_lane) {
-            const float inv = rlf(inv_l, a);
-            a0 = texs[(a * 3 + 0) * tstride + wc.lane] * inv; a1 = texs[(a * 3 + 1) * tstride + wc.lane] * inv; a2 = texs[(a * 3 + 2) * tstride + wc.lane] * inv;
+            a0 = texs[(a * 3 + 0) * tstride + wc.lane]; a1 = texs[(a * 3 + 1) * tstride + wc.lane]; a2 = texs[(a * 3 + 2) * tstride + wc.lane];
         }
-        float dot_l = 0.0f;  // view lane b: sum of products of (a, b)
+        const float inva = rlf(inv_l, a);
+        float dot_l = 0.0f;  // view lane b: sum of products of the centred textures (a, b)
         for (int b = a + 1; b < n; ++b) {
             if (oka && ((okmask >> b) & 1u)) {
                 float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
                 if (wc.sample_lane) {
-                    const float inv = rlf(inv_l, b);
-                    b0 = texs[(b * 3 + 0) * tstride + wc.lane] * inv; b1 = texs[(b * 3 + 1) * tstride + wc.lane] * inv; b2 = texs[(b * 3 + 2) * tstride + wc.lane] * inv;
+                    b0 = texs[(b * 3 + 0) * tstride + wc.lane]; b1 = texs[(b * 3 + 1) * tstride + wc.lane]; b2 = texs[(b * 3 + 2) * tstride + wc.lane];
                 }
                 const float s = tex_dot_sum(a0, a1, a2, b0, b1, b2);
                 if (wc.lane == b) dot_l = s;
             }
         }
         // view lane b > a: inccs[a][b] (2.0 when either texture is missing)
-        float val_l = robustincc(1.0f - dot_l * prm.inv_3sz);
+        float val_l = robustincc(1.0f - (dot_l * (inva * inv_l)) * prm.inv_3sz);
         if (!(oka && wc.lane < MVS_LISTCAP && ((okmask >> (wc.lane & 31)) & 1u))) val_l = 2.0f;
         if (wc.lane > a && wc.lane < n) acc += val_l;
         for (int b = a + 1; b < n; ++b) {

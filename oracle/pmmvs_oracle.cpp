@@ -182,6 +182,7 @@ struct Patch { /* patch.hpp:23-67 */
 
 struct Tex { /* one grabbed 7x7 texture: channel-major, 64 lanes, lanes >= n are zero */
     float c[3][64];
+    float inv; /* 1 / msd after normalize_tex; the samples stay centred, the scale is applied in dot_tex */
     bool ok;
 };
 
@@ -503,8 +504,10 @@ void normalize_tex(const Scene& s, Tex& tex) {
     const float ssd = reduce(s, sq, sz);
     float msd = sqrtf(ssd * s.inv_3sz);
     if (msd == 0.0f) msd = 1.0f;
-    const float inv = 1.0f / msd; /* tex / msd as multiply by the inverse (Eigen 3.2 vector/scalar) */
-    for (int i = 0; i < sz; ++i) for (int c = 0; c < 3; ++c) tex.c[c][i] *= inv;
+    /* (tex - ave) / msd, optim.cpp:937-939: the division is kept as the factor 1/msd and applied to the dot
+     * product of the centred textures (dot_tex) -- the same value up to fp reassociation, and it lets the
+     * engine reduce sum(d0*d1) without waiting for the square root. */
+    tex.inv = 1.0f / msd;
 }
 
 /* Optim::dot, optim.cpp:601-609 */
@@ -513,7 +516,7 @@ float dot_tex(const Scene& s, const Tex& a, const Tex& b) {
     float p[64];
     for (int i = 0; i < 64; ++i) p[i] = 0.0f;
     for (int i = 0; i < sz; ++i) p[i] = fma_(a.c[2][i], b.c[2][i], fma_(a.c[1][i], b.c[1][i], a.c[0][i] * b.c[0][i]));
-    return reduce(s, p, sz) * s.inv_3sz;
+    return (reduce(s, p, sz) * (a.inv * b.inv)) * s.inv_3sz;
 }
 
 /* Optim::computeUnits(patch, units), optim.cpp:109-132, then computeWeights, optim.cpp:942-948 */
@@ -1780,7 +1783,8 @@ int orc_get_tex(orc_scene* h, const float* c, const float* px, const float* py, 
     if (flag != 0) return flag;
     if (normalize) normalize_tex(h->s, t);
     const int sz = h->s.cfg.wsize * h->s.cfg.wsize;
-    for (int i = 0; i < sz; ++i) for (int ch = 0; ch < 3; ++ch) out[3 * i + ch] = t.c[ch][i];
+    const float sc = normalize ? t.inv : 1.0f;
+    for (int i = 0; i < sz; ++i) for (int ch = 0; ch < 3; ++ch) out[3 * i + ch] = t.c[ch][i] * sc;
     return 0;
 }
 float orc_compute_incc(orc_scene* h, const orc_patch* r, int robust) {
