@@ -21,6 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
+    if os.environ.get("GRAFT_REPO_ROOT"):  # on a GPU box the snapshot's prebuilt library is used as is
+        return False
     t = os.path.getmtime(LIB_PATH)
     for d in DEPS:
         p = d if os.path.isabs(d) else os.path.join(CSRC, d)
@@ -50,6 +52,8 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     """The host-side mirror of the reference classes (C++, g++), linked against the engine's C ABI."""
     src = os.path.join(HOST_DIR, "pmmvps_host.cpp")
     deps = [src, os.path.join(HOST_DIR, "pmmvps_host.hpp"), os.path.join(ROOT, "include", "mvskit_engine.h"), LIB_PATH]
+    if not force and os.path.exists(HOST_LIB_PATH) and os.environ.get("GRAFT_REPO_ROOT"):
+        return HOST_LIB_PATH
     if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
         return HOST_LIB_PATH
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", HOST_LIB_PATH,

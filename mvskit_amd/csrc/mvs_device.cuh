@@ -25,7 +25,19 @@ struct F3 { float x, y, z; };
 struct F4 { float x, y, z, w; };
 
 #define DEV __device__ __forceinline__
-#define MVS_CH 5  // non-reference views processed per chunk of an evaluation (registers: 3 floats each)
+// The stages around the refinement loop can be compiled as real calls (MVS_OUTLINE=1): their register live ranges
+// then do not interfere with the hot loop.
+#ifndef MVS_U1
+#define MVS_U1 3  // views kept in flight per step when a single proposal is evaluated
+#endif
+#ifndef MVS_OUTLINE
+#define MVS_OUTLINE 0
+#endif
+#if MVS_OUTLINE
+#define STAGE __device__ __noinline__
+#else
+#define STAGE __device__ __forceinline__
+#endif
 
 DEV int lane_id() { return (int)(threadIdx.x & 63u); }
 DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -297,13 +309,16 @@ DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int
     p.ok = rli(f.ok, e);
     const int W = rli(f.w, e);
     const float tlx = rlf(f.tlx, e), tly = rlf(f.tly, e), dxx = rlf(f.dxx, e), dxy = rlf(f.dxy, e), dyx = rlf(f.dyx, e), dyy = rlf(f.dyy, e);
-    const uint32_t* img = (const uint32_t*)(((unsigned long long)(unsigned)rli((int)f.img_hi, e) << 32) | (unsigned long long)(unsigned)rli((int)f.img_lo, e));
+    // the address is rebuilt from two readlanes: say explicitly that it is global memory, or the loads become
+    // flat_load (which count on vmcnt AND lgkmcnt and cannot stay in flight across the reductions)
+    typedef const __attribute__((address_space(1))) Texel2* GlobalTexels;
+    const unsigned long long base = ((unsigned long long)(unsigned)rli((int)f.img_hi, e) << 32) | (unsigned long long)(unsigned)rli((int)f.img_lo, e);
     const float sx = wc.sample_lane ? fma_(dyx, wc.fy, fma_(dxx, wc.fx, tlx)) : 0.0f;
     const float sy = wc.sample_lane ? fma_(dyy, wc.fy, fma_(dxy, wc.fx, tly)) : 0.0f;
     const int lx = (int)sx, ly = (int)sy;
-    const uint32_t* p0 = img + (ly * W + lx);
-    p.q0 = *reinterpret_cast<const Texel2*>(p0);
-    p.q1 = *reinterpret_cast<const Texel2*>(p0 + W);
+    const unsigned long long a0 = base + 4ull * (unsigned long long)(unsigned)(ly * W + lx);
+    p.q0 = *(GlobalTexels)a0;
+    p.q1 = *(GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)W);
     p.dx1 = sx - (float)lx; p.dy1 = sy - (float)ly;
     return p;
 }
@@ -337,46 +352,51 @@ DEV float inv_msd(const DParams& prm, float ssd) {
 // Leaves in frame lane 16*g + k (k >= 1) the INCC of view k against the reference of proposal g,
 //     1 - (sum(d0*dk) * (inv0 * invk)) / (3*sz)              (Optim::dot on normalised textures, optim.cpp:601-609)
 // and in okm[g] the bit mask of views that were sampled.  One sqrt/division sequence serves all NP*n views.
-template <int NP>
+// NP*U independent sampling chains are kept in flight per step (U consecutive views of each proposal), and the
+// loads of the next step are issued before the current step is reduced.
+template <int NP, int U>
 DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[NP], float& incc_l) {
+    constexpr int NS = NP * U;
     float d0[NP][3];
     float ssd_l = 1.0f, dot_l = 0.0f;
-    Pending pn[NP];
+    Pending pr[NP], pn[NS];
 #pragma unroll
-    for (int g = 0; g < NP; ++g) { okm[g] = 0u; pn[g] = tex_issue(prm, wc, f, 16 * g); }
-    {
-        Pending p[NP];
+    for (int g = 0; g < NP; ++g) { okm[g] = 0u; pr[g] = tex_issue(prm, wc, f, 16 * g); }
 #pragma unroll
-        for (int g = 0; g < NP; ++g) p[g] = pn[g];
-        if (n > 1) {
+    for (int g = 0; g < NP; ++g)
 #pragma unroll
-            for (int g = 0; g < NP; ++g) pn[g] = tex_issue(prm, wc, f, 16 * g + 1);
-        }
+        for (int u = 0; u < U; ++u) pn[g * U + u] = tex_issue(prm, wc, f, 16 * g + min(1 + u, n - 1));
 #pragma unroll
-        for (int g = 0; g < NP; ++g) {
-            tex_centre(prm, wc, p[g], d0[g][0], d0[g][1], d0[g][2]);
-            const float s = ssd_sum(d0[g][0], d0[g][1], d0[g][2]);
-            okm[g] |= (unsigned)p[g].ok;
-            if (wc.lane == 16 * g) ssd_l = s;
-        }
+    for (int g = 0; g < NP; ++g) {
+        tex_centre(prm, wc, pr[g], d0[g][0], d0[g][1], d0[g][2]);
+        const float s = ssd_sum(d0[g][0], d0[g][1], d0[g][2]);
+        okm[g] |= (unsigned)pr[g].ok;
+        if (wc.lane == 16 * g) ssd_l = s;
     }
-    for (int k = 1; k < n; ++k) {
-        Pending p[NP];
+    for (int k0 = 1; k0 < n; k0 += U) {
+        Pending p[NS];
 #pragma unroll
-        for (int g = 0; g < NP; ++g) p[g] = pn[g];
-        if (k + 1 < n) {
+        for (int q = 0; q < NS; ++q) p[q] = pn[q];
+        if (k0 + U < n) {
 #pragma unroll
-            for (int g = 0; g < NP; ++g) pn[g] = tex_issue(prm, wc, f, 16 * g + k + 1);
+            for (int g = 0; g < NP; ++g)
+#pragma unroll
+                for (int u = 0; u < U; ++u) pn[g * U + u] = tex_issue(prm, wc, f, 16 * g + min(k0 + U + u, n - 1));
         }
 #pragma unroll
-        for (int g = 0; g < NP; ++g) {
-            float e0, e1, e2;
-            tex_centre(prm, wc, p[g], e0, e1, e2);
-            const float s = ssd_sum(e0, e1, e2);
-            const float dt = tex_dot_sum(d0[g][0], d0[g][1], d0[g][2], e0, e1, e2);
-            okm[g] |= (unsigned)p[g].ok << k;
-            if (wc.lane == 16 * g + k) { ssd_l = s; dot_l = dt; }
-        }
+        for (int g = 0; g < NP; ++g)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u;
+                float e0, e1, e2;
+                tex_centre(prm, wc, p[g * U + u], e0, e1, e2);
+                const float s = ssd_sum(e0, e1, e2);
+                const float dt = tex_dot_sum(d0[g][0], d0[g][1], d0[g][2], e0, e1, e2);
+                if (k < n) {
+                    okm[g] |= (unsigned)p[g * U + u].ok << k;
+                    if (wc.lane == 16 * g + k) { ssd_l = s; dot_l = dt; }
+                }
+            }
     }
     // the metric's work count: views that sampled; nothing counts when the reference view itself was rejected
     // (Optim::cost_func / computeINCC / setINCCs return before looking at the others, optim.cpp:448,657,725)
@@ -429,7 +449,7 @@ DEV float compute_incc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < sz);
     unsigned okm[1];
     float incc_l;
-    eval_core<1>(prm, wc, f, sz, okm, incc_l);
+    eval_core<1, MVS_U1>(prm, wc, f, sz, okm, incc_l);
     if (!(okm[0] & 1u)) return 2.0f;
     const float val_l = robust ? robustincc(incc_l) : incc_l;
     float score = 0.0f, total = 0.0f;
@@ -457,7 +477,7 @@ DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int im
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < n);
     unsigned okm[1];
     float incc_l;
-    eval_core<1>(prm, wc, f, n, okm, incc_l);
+    eval_core<1, MVS_U1>(prm, wc, f, n, okm, incc_l);
     if (!(okm[0] & 1u)) return 2.0f;
     float incc = robust ? robustincc(incc_l) : incc_l;
     if (wc.lane >= MVS_LISTCAP || !((okm[0] >> (wc.lane & 31)) & 1u)) incc = 2.0f;
@@ -581,7 +601,7 @@ DEV int check_angles(const DParams& prm, const WaveCtx& wc, const Cand& c) {
 }
 
 // Optim::preProcess, optim.cpp:137-163
-DEV int pre_process(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c) {
+STAGE int pre_process(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c) {
     add_images(prm, wc, scratch, c);
     constraint_images(prm, wc, scratch, c, prm.nccThresholdBefore);
     sort_images(prm, wc, c);
@@ -656,7 +676,7 @@ DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
     if (three) {
         wc.evals += 3;
         unsigned okm[3];
-        eval_core<3>(prm, wc, f, sz, okm, incc_l);
+        eval_core<3, 1>(prm, wc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
         f0 = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
         f1 = cost_of_group(prm, wc, okm[1], val_l, 1, sz, minimum);
@@ -664,13 +684,13 @@ DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
     } else {
         wc.evals += 1;
         unsigned okm[1];
-        eval_core<1>(prm, wc, f, sz, okm, incc_l);
+        eval_core<1, MVS_U1>(prm, wc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
         f0 = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
     }
 }
 // Optim::refinePatch, optim.cpp:480-547, BOBYQA replaced by the halving random search
-DEV void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
     RefineCtx rc;
     rc.center = c.coord;
     rc.ref = rli(c.img, 0);
@@ -730,7 +750,9 @@ DEV void set_grids(const DParams& prm, const WaveCtx& wc, Cand& c) {
     if (wc.lane < c.nimg) cell_of(prm, prm.views + c.img, c.coord, c.gx, c.gy);
 }
 // Optim::setRefImage, optim.cpp:348-383 with Optim::setINCCs (matrix), optim.cpp:748-783.
-// texs: LDS [LISTCAP][3][tstride] normalised textures.
+// texs: LDS [LISTCAP][3][tstride] centred textures.  The V(V-1)/2 pair products get one lane each and are summed
+// over the samples in the reference's sequential order (optim.cpp:605-607).
+DEV int pair_index(int a, int b, int n) { return a * (2 * n - a - 1) / 2 + (b - a - 1); }  // a < b < n
 DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride, Cand& c) {
     if (c.nimg == 0) return;
     const int n = c.nimg;
@@ -741,55 +763,69 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     const Frame f = make_frame(prm, c.coord, px, py, c.normal, c.img, wc.lane < n);
     unsigned okmask = 0;
     __syncthreads();
-    // centred textures to LDS, their ssd to view lanes; then one sqrt/division sequence for all views
+    // centred textures to LDS (three views in flight per step), their ssd to view lanes
     float ssd_l = 1.0f;
     {
-        Pending pn = tex_issue(prm, wc, f, 0);
-        for (int i = 0; i < n; ++i) {
-            const Pending p = pn;
-            if (i + 1 < n) pn = tex_issue(prm, wc, f, i + 1);
-            float t0, t1, t2;
-            tex_centre(prm, wc, p, t0, t1, t2);
-            const float s = ssd_sum(t0, t1, t2);
-            okmask |= (unsigned)p.ok << i;
-            wc.view_evals += (unsigned)p.ok;
-            if (wc.lane == i) ssd_l = s;
-            if (wc.sample_lane) {
-                texs[(i * 3 + 0) * tstride + wc.lane] = t0;
-                texs[(i * 3 + 1) * tstride + wc.lane] = t1;
-                texs[(i * 3 + 2) * tstride + wc.lane] = t2;
+        Pending pn[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) pn[u] = tex_issue(prm, wc, f, min(u, n - 1));
+        for (int i0 = 0; i0 < n; i0 += 3) {
+            Pending p[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) p[u] = pn[u];
+            if (i0 + 3 < n) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) pn[u] = tex_issue(prm, wc, f, min(i0 + 3 + u, n - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = i0 + u;
+                float t0, t1, t2;
+                tex_centre(prm, wc, p[u], t0, t1, t2);
+                const float s = ssd_sum(t0, t1, t2);
+                if (i < n) {
+                    okmask |= (unsigned)p[u].ok << i;
+                    wc.view_evals += (unsigned)p[u].ok;
+                    if (wc.lane == i) ssd_l = s;
+                    if (wc.sample_lane) {
+                        texs[(i * 3 + 0) * tstride + wc.lane] = t0;
+                        texs[(i * 3 + 1) * tstride + wc.lane] = t1;
+                        texs[(i * 3 + 2) * tstride + wc.lane] = t2;
+                    }
+                }
             }
         }
     }
     const float inv_l = inv_msd(prm, ssd_l);
     __syncthreads();
-    float acc = 0.0f;  // view lane i: sum_j inccs[i][j], j ascending
-    for (int a = 0; a < n; ++a) {
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-        const bool oka = (okmask >> a) & 1u;
-        if (oka && wc.sample_lane) {
-            a0 = texs[(a * 3 + 0) * tstride + wc.lane]; a1 = texs[(a * 3 + 1) * tstride + wc.lane]; a2 = texs[(a * 3 + 2) * tstride + wc.lane];
-        }
-        const float inva = rlf(inv_l, a);
-        float dot_l = 0.0f;  // view lane b: sum of products of the centred textures (a, b)
-        for (int b = a + 1; b < n; ++b) {
-            if (oka && ((okmask >> b) & 1u)) {
-                float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-                if (wc.sample_lane) {
-                    b0 = texs[(b * 3 + 0) * tstride + wc.lane]; b1 = texs[(b * 3 + 1) * tstride + wc.lane]; b2 = texs[(b * 3 + 2) * tstride + wc.lane];
-                }
-                const float s = tex_dot_sum(a0, a1, a2, b0, b1, b2);
-                if (wc.lane == b) dot_l = s;
-            }
-        }
-        // view lane b > a: inccs[a][b] (2.0 when either texture is missing)
-        float val_l = robustincc(1.0f - (dot_l * (inva * inv_l)) * prm.inv_3sz);
-        if (!(oka && wc.lane < MVS_LISTCAP && ((okmask >> (wc.lane & 31)) & 1u))) val_l = 2.0f;
-        if (wc.lane > a && wc.lane < n) acc += val_l;
-        for (int b = a + 1; b < n; ++b) {
-            const float v = rlf(val_l, b);
-            if (wc.lane == a) acc += v;
-        }
+    // one lane per pair (a, b), a < b < n; up to 120 pairs = 2 rounds of 64 lanes
+    const int npairs = n * (n - 1) / 2;
+    float val0 = 2.0f, val1 = 2.0f;  // robust INCC of pair lane + 64 * round
+    for (int r = 0; r * 64 < npairs; ++r) {
+        int q = wc.lane + 64 * r;
+        const bool act = q < npairs;
+        int a = 0;
+        if (act) { while (q >= n - 1 - a) { q -= n - 1 - a; ++a; } }
+        const int b = act ? a + 1 + q : 1;
+        const float* ta = texs + (a * 3) * tstride;
+        const float* tb = texs + (b * 3) * tstride;
+        float acc = 0.0f;
+        for (int i = 0; i < prm.wsz; ++i)
+            acc += fma_(ta[2 * tstride + i], tb[2 * tstride + i], fma_(ta[tstride + i], tb[tstride + i], ta[i] * tb[i]));
+        const float inva = __shfl(inv_l, a), invb = __shfl(inv_l, b);
+        float val = robustincc(1.0f - (acc * (inva * invb)) * prm.inv_3sz);
+        if (!(act && ((okmask >> a) & 1u) && ((okmask >> b) & 1u))) val = 2.0f;
+        if (r == 0) val0 = val; else val1 = val;
+    }
+    // view lane i: sum over j of inccs[i][j], j ascending (std::accumulate, optim.cpp:368)
+    float acc = 0.0f;
+    for (int j = 0; j < n; ++j) {
+        const int i = min(wc.lane, n - 1);
+        const int a = min(i, j), b = max(i, j);
+        const int q = a < b ? pair_index(a, b, n) : 0;
+        const float v0 = __shfl(val0, q & 63), v1 = __shfl(val1, q & 63);
+        const float v = (q >> 6) ? v1 : v0;
+        if (wc.lane < n && wc.lane != j) acc += v;
     }
     const float big = (float)(INT_MAX / 2);
     const bool cand = wc.lane < n && acc < big;
@@ -854,7 +890,7 @@ DEV int get_mask_all(const DParams& prm, const WaveCtx& wc, const Cand& c) {
 DEV float score2(const Cand& c, float thr) { return fmaxf(0.0f, c.ncc - thr) * (float)c.nimg; }
 
 // Optim::postProcess, optim.cpp:260-298 (Optim::check is applied by the caller, which owns the cell lists)
-DEV int post_process(const DParams& prm, WaveCtx& wc, int* scratch, float* texs, int tstride, Cand& c) {
+STAGE int post_process(const DParams& prm, WaveCtx& wc, int* scratch, float* texs, int tstride, Cand& c) {
     if (c.nimg < prm.minImageNum) return -1;
     if (get_mask_all(prm, wc, c) == 0) return -1;
     add_images(prm, wc, scratch, c);
@@ -905,7 +941,7 @@ DEV WaveCtx make_wave_ctx(const DParams& prm) {
 }
 
 // Propagate::generatePatch, propagate.cpp:220-237.  `src` is in registers (view lanes hold m_images).
-DEV bool generate_patch(const DParams& prm, WaveCtx& wc, int* scratch, const Cand& src, F3 icoord, Cand& out) {
+STAGE bool generate_patch(const DParams& prm, WaveCtx& wc, int* scratch, const Cand& src, F3 icoord, Cand& out) {
     const int image = rli(src.img, 0);
     const DView* vw = prm.views + image;
     const float depth = dot4(ld4(vw->oaxis), src.coord);

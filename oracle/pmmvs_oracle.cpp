@@ -593,7 +593,13 @@ void set_inccs_matrix(const Scene& s, const Patch& p, const int* idx, int n, int
         for (int j = i + 1; j < n; ++j) {
             float val = 2.0f;
             if (t[i].ok && t[j].ok) {
-                const float d = 1.0f - dot_tex(s, t[i], t[j]);
+                /* the V x V pair products are always summed in the reference's sequential sample order
+                 * (optim.cpp:605-607), whatever sum_mode says: the engine gives one lane to each pair */
+                const int sz = s.cfg.wsize * s.cfg.wsize;
+                float acc = 0.0f;
+                for (int q = 0; q < sz; ++q)
+                    acc += fma_(t[i].c[2][q], t[j].c[2][q], fma_(t[i].c[1][q], t[j].c[1][q], t[i].c[0][q] * t[j].c[0][q]));
+                const float d = 1.0f - (acc * (t[i].inv * t[j].inv)) * s.inv_3sz;
                 val = robust ? robustincc(d) : d;
             }
             inccs[i * n + j] = inccs[j * n + i] = val;
