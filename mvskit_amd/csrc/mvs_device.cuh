@@ -28,7 +28,7 @@ struct F4 { float x, y, z, w; };
 // The stages around the refinement loop can be compiled as real calls (MVS_OUTLINE=1): their register live ranges
 // then do not interfere with the hot loop.
 #ifndef MVS_U1
-#define MVS_U1 3  // views kept in flight per step when a single proposal is evaluated
+#define MVS_U1 1  // views kept in flight per step when a single proposal is evaluated (3 is faster in isolation, 1 in the fused sweep: registers)
 #endif
 #ifndef MVS_OUTLINE
 #define MVS_OUTLINE 0
@@ -311,14 +311,15 @@ DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int
     const float tlx = rlf(f.tlx, e), tly = rlf(f.tly, e), dxx = rlf(f.dxx, e), dxy = rlf(f.dxy, e), dyx = rlf(f.dyx, e), dyy = rlf(f.dyy, e);
     // the address is rebuilt from two readlanes: say explicitly that it is global memory, or the loads become
     // flat_load (which count on vmcnt AND lgkmcnt and cannot stay in flight across the reductions)
-    typedef const __attribute__((address_space(1))) Texel2* GlobalTexels;
+    typedef const __attribute__((address_space(1))) uint32_t* GlobalTexels;
     const unsigned long long base = ((unsigned long long)(unsigned)rli((int)f.img_hi, e) << 32) | (unsigned long long)(unsigned)rli((int)f.img_lo, e);
     const float sx = wc.sample_lane ? fma_(dyx, wc.fy, fma_(dxx, wc.fx, tlx)) : 0.0f;
     const float sy = wc.sample_lane ? fma_(dyy, wc.fy, fma_(dxy, wc.fx, tly)) : 0.0f;
     const int lx = (int)sx, ly = (int)sy;
     const unsigned long long a0 = base + 4ull * (unsigned long long)(unsigned)(ly * W + lx);
-    p.q0 = *(GlobalTexels)a0;
-    p.q1 = *(GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)W);
+    const GlobalTexels t0 = (GlobalTexels)a0, t1 = (GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)W);
+    p.q0.a = t0[0]; p.q0.b = t0[1];
+    p.q1.a = t1[0]; p.q1.b = t1[1];
     p.dx1 = sx - (float)lx; p.dy1 = sy - (float)ly;
     return p;
 }
