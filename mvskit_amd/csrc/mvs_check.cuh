@@ -1,0 +1,333 @@
+// mvs_check.cuh -- Optim::check (pmmvps/optim.cpp:300-323) for one candidate, one wavefront.
+//   Filter::computeGain      filter.cpp:108-146      view lanes, each walking the list of its cell
+//   PatchManager::findNeighbors patch_manager.cpp:671-728  lanes over (image, cell) pairs, ids into an LDS hash set,
+//                                                     then sorted ascending (the oracle's std::sort + unique order)
+//   Filter::filterQuad       filter.cpp:329-392      rows lane-parallel, sums in the reference's sequential order
+//   Filter::lls              filter.cpp:411-430      normal equations + pivoted elimination in double (as the oracle)
+// Lists of other cells/views are read from the pass snapshot (CSR, dead entries skipped); the list of the
+// destination cell being processed is the live one, published by the caller in LDS.
+#pragma once
+#include "mvs_device.cuh"
+
+namespace mvsdev {
+
+#define MVS_HASH_CAP 1024  // ints: hash set / sorted id list of the neighbours
+#define MVS_ROW_CAP 512    // neighbours kept for filterQuad (3 floats each)
+#define MVS_CHECK_LDS_FLOATS (MVS_HASH_CAP + 3 * MVS_ROW_CAP)
+
+struct CheckCtx {
+    const DPatch* staging;  // records created by this pass (ids >= MVS_NEWBASE)
+    int live_view, live_cell, live_n;
+    const int* live_ids;    // LDS: the destination cell's current list
+};
+
+DEV const DPatch* patch_ptr(const DParams& prm, const CheckCtx& cx, int id) {
+    return id >= MVS_NEWBASE ? cx.staging + (id - MVS_NEWBASE) : prm.pool + id;
+}
+
+// geometry of a patch needed by the neighbour predicates
+struct PGeo { F4 coord, normal; float dscale, ncc; int ref; };
+DEV PGeo load_geo(const DPatch* p) { return {ld4(p->coord), ld4(p->normal), p->dscale, p->ncc, (int)p->images[0]}; }
+
+// PmMvps::isNeighbor, pmmvps.cpp:117-147 (deg/rad typo at :124 kept)
+DEV int is_neighbor_h(const DParams& prm, const PGeo& l, const PGeo& r, float hunit, float thr) {
+    if (dot4(l.normal, r.normal) < prm.cosNeighborTypo) return 0;
+    const F4 diff = sub4(l.coord, r.coord);
+    const float vunit = l.dscale + r.dscale;
+    const float f0 = dot4(l.normal, diff), f1 = dot4(r.normal, diff);
+    float ftmp = (fabsf(f0) + fabsf(f1)) / 2.0f;
+    ftmp /= vunit;
+    const F4 h = add4(sub4(diff, mul4(l.normal, f0)), sub4(diff, mul4(r.normal, f1)));
+    const float hsize = norm4(h) / 2.0f / hunit;
+    if (1.0f < hsize) ftmp /= fminf(2.0f, hsize);
+    return ftmp < thr ? 1 : 0;
+}
+DEV int is_neighbor(const DParams& prm, const PGeo& l, const PGeo& r, float thr) {
+    const float hunit = (get_unit(prm, prm.views + l.ref, l.coord) + get_unit(prm, prm.views + r.ref, r.coord)) / 2.0f * (float)prm.csize;
+    return is_neighbor_h(prm, l, r, hunit, thr);
+}
+// PmMvps::isNeighborRadius, pmmvps.cpp:149-180
+DEV int is_neighbor_radius(const DParams& prm, const PGeo& l, const PGeo& r, float hunit, float thr, float radius) {
+    if (dot4(l.normal, r.normal) < prm.cosNeighbor120) return 0;
+    const F4 diff = sub4(r.coord, l.coord);
+    const float vunit = l.dscale + r.dscale;
+    const float f0 = dot4(l.normal, diff), f1 = dot4(r.normal, diff);
+    float ftmp = (fabsf(f0) + fabsf(f1)) / 2.0f;
+    ftmp /= vunit;
+    const F4 h = sub4(sub4(mul4(diff, 2.0f), mul4(l.normal, f0)), mul4(r.normal, f1));
+    const float hsize = norm4(h) / 2.0f / hunit;
+    if (radius / hunit < hsize) return 0;
+    if (1.0f < hsize) ftmp /= fminf(2.0f, hsize);
+    return ftmp < thr ? 1 : 0;
+}
+
+// list of (kind, view, cell): kind 0 = m_pgrids, 1 = m_vpgrids.  Returns [b, e) into ids, or the live list.
+DEV void cell_span(const DParams& prm, const CheckCtx& cx, int kind, int view, int cell, const int*& ids, int& n, bool& live) {
+    live = kind == 0 && view == cx.live_view && cell == cx.live_cell;
+    if (live) { ids = cx.live_ids; n = cx.live_n; return; }
+    const DView* vw = prm.views + view;
+    const int g = vw->cell_base + cell;
+    const int* st = kind == 0 ? prm.csr_start : prm.vcsr_start;
+    const int* id = kind == 0 ? prm.csr_ids : prm.vcsr_ids;
+    ids = id + st[g];
+    n = st[g + 1] - st[g];
+}
+
+// Filter::computeGain, filter.cpp:108-146
+DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c) {
+    const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
+    float gain = score2(c, prm.nccThreshold);
+    float maxp = 0.0f;
+    if (wc.lane < c.nimg) {
+        const int v = c.img;
+        const int cell = c.gy * (prm.views + v)->gw + c.gx;
+        const int* ids; int n; bool live;
+        cell_span(prm, cx, 0, v, cell, ids, n, live);
+        for (int j = 0; j < n; ++j) {
+            const DPatch* q = patch_ptr(prm, cx, ids[j]);
+            if (!live && !(q->flags & 1)) continue;
+            const PGeo g = load_geo(q);
+            if (!is_neighbor(prm, me, g, prm.neighborThreshold1)) maxp = fmaxf(maxp, g.ncc - prm.nccThreshold);
+        }
+    }
+    for (int i = 0; i < c.nimg; ++i) gain -= rlf(maxp, i);
+    maxp = 0.0f;
+    if (wc.lane < c.nvimg) {
+        const int v = c.vimg;
+        const DView* vw = prm.views + v;
+        const float pdepth = dot4(ld4(vw->oaxis), c.coord);
+        const int cell = c.vgy * vw->gw + c.vgx;
+        const int* ids; int n; bool live;
+        cell_span(prm, cx, 0, v, cell, ids, n, live);
+        for (int j = 0; j < n; ++j) {
+            const DPatch* q = patch_ptr(prm, cx, ids[j]);
+            if (!live && !(q->flags & 1)) continue;
+            const PGeo g = load_geo(q);
+            const float bdepth = dot4(ld4(vw->oaxis), g.coord);
+            if (pdepth < bdepth && !is_neighbor(prm, me, g, prm.neighborThreshold1)) maxp = fmaxf(maxp, g.ncc - prm.nccThreshold);
+        }
+    }
+    for (int i = 0; i < c.nvimg; ++i) gain -= rlf(maxp, i);
+    return gain;
+}
+
+// PatchManager::findNeighbors, patch_manager.cpp:671-728 (scale 4, margin 2 as Optim::check calls it).
+// Leaves the sorted unique ids in `table[0..count)` (LDS, MVS_HASH_CAP ints) and returns count.
+DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin) {
+    const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
+    // Propagate::computeRadius, propagate.cpp:474-481: the second smallest unit
+    float u = __int_as_float(0x7f800000);
+    if (wc.lane < c.nimg) {
+        const DView* vw = prm.views + c.img;
+        u = get_unit(prm, vw, c.coord);
+        const F4 ray = nrm4(sub4(ld4(vw->center), c.coord));
+        const float d = dot4(ray, c.normal);
+        if (0.0f < d) u /= d; else u = (float)(INT_MAX / 2);
+    }
+    const float m1 = wave_min(u);
+    const unsigned long long eq = ballot(wc.lane < c.nimg && u == m1);
+    const int first = __ffsll((long long)eq) - 1;
+    const float m2 = wave_min(wc.lane == first ? __int_as_float(0x7f800000) : u);
+    const float second = c.nimg > 1 ? m2 : m1;
+    const float radius = (float)(1.5 * (double)margin * (double)(second * (float)prm.csize));
+    float unit = 0.0f;
+    {
+        float gu = 0.0f;
+        if (wc.lane < c.nimg) gu = get_unit(prm, prm.views + c.img, c.coord);
+        for (int i = 0; i < c.nimg; ++i) unit += rlf(gu, i);
+        unit /= (float)c.nimg;
+        unit *= (float)prm.csize;
+    }
+    const float thr = prm.neighborThreshold * scale;
+    __syncthreads();
+    for (int t = wc.lane; t < MVS_HASH_CAP; t += 64) table[t] = -1;
+    __syncthreads();
+    const int side = 2 * margin + 1, per = side * side;
+    const int ntask = c.nimg * per;
+    for (int t0 = 0; t0 < ntask; t0 += 64) {
+        const int t = t0 + wc.lane;
+        const int i = min(t / per, c.nimg - 1), r = t % per;
+        const int v = __shfl(c.img, i), gx = __shfl(c.gx, i), gy = __shfl(c.gy, i);  // all lanes take part in the shuffles
+        if (t < ntask) {
+            const DView* vw = prm.views + v;
+            const int yt = gy + r / side - margin, xt = gx + r % side - margin;
+            if (!(yt < 0 || vw->gh <= yt || xt < 0 || vw->gw <= xt)) {
+                const int cell = yt * vw->gw + xt;
+                for (int kind = 0; kind < 2; ++kind) {
+                    const int* ids; int n; bool live;
+                    cell_span(prm, cx, kind, v, cell, ids, n, live);
+                    for (int j = 0; j < n; ++j) {
+                        const int id = ids[j];
+                        const DPatch* q = patch_ptr(prm, cx, id);
+                        if (!live && !(q->flags & 1)) continue;
+                        if (!is_neighbor_radius(prm, me, load_geo(q), unit, thr, radius)) continue;
+                        unsigned h = (mix32((uint32_t)id)) & (MVS_HASH_CAP - 1);
+                        for (int probe = 0; probe < MVS_HASH_CAP; ++probe) {
+                            const int old = atomicCAS(&table[h], -1, id);
+                            if (old == -1 || old == id) break;
+                            h = (h + 1) & (MVS_HASH_CAP - 1);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // compact the set to the front of the table (through a second region: the upper half is not needed once read)
+    int count = 0;
+    int mine[MVS_HASH_CAP / 64];
+#pragma unroll
+    for (int k = 0; k < MVS_HASH_CAP / 64; ++k) mine[k] = table[k * 64 + wc.lane];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MVS_HASH_CAP / 64; ++k) {
+        const bool has = mine[k] != -1;
+        const unsigned long long m = ballot(has);
+        if (has) table[count + __popcll(m & ((1ull << wc.lane) - 1ull))] = mine[k];
+        count += __popcll(m);
+    }
+    __syncthreads();
+    // bitonic sort ascending of table[0..count), padded with INT_MAX to a power of two
+    int npad = 64;
+    while (npad < count) npad <<= 1;
+    for (int t = count + wc.lane; t < npad; t += 64) table[t] = INT_MAX;
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = wc.lane; t < npad; t += 64) {
+                const int ixj = t ^ j;
+                if (ixj > t) {
+                    const int a = table[t], b = table[ixj];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { table[t] = b; table[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    return count;
+}
+
+// Filter::ortho, filter.cpp:394-409
+DEV void ortho(F4 z, F4& x, F4& y) {
+    if (fabsf(z.x) > 0.5f) x = {z.y, -z.x, 0.0f, 0.0f};
+    else if (fabsf(z.y) > 0.5f) x = {0.0f, z.z, -z.y, 0.0f};
+    else x = {-z.z, 0.0f, z.x, 0.0f};
+    const float n = norm4(x);
+    x = {x.x / n, x.y / n, x.z / n, x.w / n};
+    y = {z.y * x.z - z.z * x.y, z.z * x.x - z.x * x.z, z.x * x.y - z.y * x.x, 0.0f};
+}
+
+// Filter::filterQuad, filter.cpp:329-392.  nb = sorted ids in LDS (n of them); rows = LDS scratch of 3*n floats
+// (fx, fy, fz per neighbour; the five regressors fx^2, fy^2, fx*fy, fx, fy are re-formed from them).
+DEV float quad_term(int k, float fx, float fy, float fz) {
+    return k == 0 ? fx * fx : k == 1 ? fy * fy : k == 2 ? fx * fy : k == 3 ? fx : k == 4 ? fy : fz;
+}
+DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, const int* nb, int n, float* rows) {
+    F4 xdir, ydir;
+    ortho(c.normal, xdir, ydir);
+    // h = mean distance, summed in neighbour order
+    for (int t = wc.lane; t < n; t += 64) rows[t] = norm4(sub4(ld4(patch_ptr(prm, cx, nb[t])->coord), c.coord));
+    __syncthreads();
+    float h = 0.0f;
+    for (int t = 0; t < n; ++t) h += rows[t];
+    h /= (float)n;
+    __syncthreads();
+    for (int t = wc.lane; t < n; t += 64) {
+        const F4 diff = sub4(ld4(patch_ptr(prm, cx, nb[t])->coord), c.coord);
+        rows[3 * t + 0] = dot4(diff, xdir) / h; rows[3 * t + 1] = dot4(diff, ydir) / h; rows[3 * t + 2] = dot4(diff, c.normal);
+    }
+    __syncthreads();
+    // Filter::lls: M[i][j] += A[r][i] * A[r][j], M[i][5] += A[r][i] * b[r]; lane 6*i + j holds M[i][j]
+    double macc = 0.0;
+    const int mi = wc.lane / 6, mj = wc.lane % 6;
+    if (wc.lane < 30) {
+        for (int r = 0; r < n; ++r) {
+            const float fx = rows[3 * r], fy = rows[3 * r + 1], fz = rows[3 * r + 2];
+            macc += (double)quad_term(mi, fx, fy, fz) * (double)quad_term(mj, fx, fy, fz);
+        }
+    }
+    double M[5][6];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(macc) & 0xffffffffll), 6 * i + j);
+            const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(macc) >> 32), 6 * i + j);
+            M[i][j] = __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+        }
+    double x[5] = {0, 0, 0, 0, 0};
+    bool solved = true;
+#pragma unroll
+    for (int col = 0; col < 5; ++col) {
+        int piv = col;
+        double best = fabs(M[col][col]);
+#pragma unroll
+        for (int r = col + 1; r < 5; ++r) {
+            const double av = fabs(M[r][col]);
+            if (av > best) { best = av; piv = r; }
+        }
+#pragma unroll
+        for (int r = col + 1; r < 5; ++r) {
+            if (piv == r) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { const double tmp = M[col][k]; M[col][k] = M[r][k]; M[r][k] = tmp; }
+            }
+        }
+        if (fabs(M[col][col]) < 1e-30) solved = false;
+        if (solved) {
+#pragma unroll
+            for (int r = col + 1; r < 5; ++r) {
+                const double f = M[r][col] / M[col][col];
+#pragma unroll
+                for (int k = col; k < 6; ++k) M[r][k] -= f * M[col][k];
+            }
+        }
+    }
+    if (solved) {
+#pragma unroll
+        for (int r = 4; r >= 0; --r) {
+            double acc = M[r][5];
+#pragma unroll
+            for (int k = r + 1; k < 5; ++k) acc -= M[r][k] * x[k];
+            x[r] = acc / M[r][r];
+        }
+    }
+    const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3], x4 = (float)x[4];
+    const int inum = min(prm.tau, c.nimg);
+    float unit = 0.0f;
+    {
+        float gu = 0.0f;
+        if (wc.lane < inum) gu = get_unit(prm, prm.views + c.img, c.coord);
+        for (int i = 0; i < inum; ++i) unit += rlf(gu, i);
+        unit /= (float)inum;
+    }
+    __syncthreads();
+    for (int t = wc.lane; t < n; t += 64) {
+        const float fx = rows[3 * t], fy = rows[3 * t + 1], fz = rows[3 * t + 2];
+        const float res = x0 * (fx * fx) + x1 * (fy * fy) + x2 * (fx * fy) + x3 * fx + x4 * fy - fz;
+        rows[3 * t] = fabsf(res) / unit;
+    }
+    __syncthreads();
+    float residual = 0.0f;
+    for (int t = 0; t < n; ++t) residual += rows[3 * t];
+    residual /= (float)(n - 5);
+    return residual < prm.quadThreshold ? 0 : 1;
+}
+
+// Optim::check, optim.cpp:300-323.  lds: MVS_CHECK_LDS_FLOATS floats (the kernel's dynamic LDS region).
+// Returns 1 when the patch is rejected.  Neighbours beyond MVS_ROW_CAP are ignored (and flagged in *overflow).
+DEV int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, Cand& c, float* lds, int* overflow) {
+    const float gain = compute_gain(prm, wc, cx, c);
+    c.tmp = gain;
+    if (gain < 0.0f) { c.nimg = 0; return 1; }
+    int* table = reinterpret_cast<int*>(lds);
+    int n = find_neighbors(prm, wc, cx, c, table, 4.0f, 2);
+    if (6 < n) {
+        if (n > MVS_ROW_CAP) { n = MVS_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }
+        if (filter_quad(prm, wc, cx, c, table, n, lds + MVS_HASH_CAP)) { c.nimg = 0; return 1; }
+    }
+    return 0;
+}
+
+}  // namespace mvsdev

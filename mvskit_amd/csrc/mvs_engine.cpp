@@ -530,7 +530,6 @@ int mvs_engine_download_patches(mvs_engine* e, int64_t cap, mvs_patch* out, int6
 int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     if (!e || !e->have_views) { g_err = "mvs_engine_pass: views not set"; return MVS_ERR_STATE; }
     if (e->staged) { g_err = "mvs_engine_pass: the previous pass was not committed"; return MVS_ERR_STATE; }
-    if (e->prm.depth >= 2 && e->prm.enable_check) { g_err = "mvs_engine_pass: Optim::check (depth >= 2) is not built into this engine yet; set enable_check = 0"; return MVS_ERR_ARG; }
     HIPCHK(hipSetDevice(e->cfg.device));
     hipStream_t st = e->stream;
     HIPCHK(hipEventRecord(e->ev[0], st));
@@ -580,7 +579,8 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
         out->fail0 = (int64_t)hc.fail0; out->fail1 = (int64_t)hc.fail1; out->inserted = (int64_t)hc.inserted; out->replaced = (int64_t)hc.replaced;
         out->evals = (int64_t)(hc.evals + fill[0]); out->view_evals = (int64_t)(hc.view_evals + fill[1]); out->trimmed = (int64_t)trimmed;
     }
-    if (herr) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
+    if (herr & 3) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
+    if (herr & 4) { g_err = "mvs_engine_pass: Optim::check met more than 512 neighbours of one patch (engine limit)"; return MVS_ERR_CAPACITY; }
     return MVS_OK;
 }
 
@@ -700,7 +700,7 @@ int mvs_engine_probe(mvs_engine* e, int op, int64_t n, const mvs_patch* in_rec, 
     hipStream_t st = e->stream;
     if (op == MVS_PROBE_POSTPROCESS && e->prm.depth > 0) if (int r = build_index(e, nullptr)) return r;  // setVImagesVGrids reads m_dpgrids
     const int64_t nf_out = op == MVS_PROBE_MATH ? 5 * n : n;
-    if (e->tmp_rec_in.ensure(n) || e->tmp_rec_out.ensure(n) || e->tmp_f_in.ensure(n) || e->tmp_f_out.ensure(nf_out) || e->tmp_i.ensure(n)) return MVS_ERR_HIP;
+    if (e->tmp_rec_in.ensure(n) || e->tmp_rec_out.ensure(n) || e->tmp_f_in.ensure(n) || e->tmp_f_out.ensure(nf_out) || e->tmp_i.ensure(n + 1)) return MVS_ERR_HIP;
     if (op == MVS_PROBE_MATH) {
         if (!in_f || !out_f) return MVS_ERR_ARG;
         HIPCHK(hipMemcpyAsync(e->tmp_f_in.p, in_f, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
@@ -708,7 +708,7 @@ int mvs_engine_probe(mvs_engine* e, int op, int64_t n, const mvs_patch* in_rec, 
         if (!in_rec) return MVS_ERR_ARG;
         HIPCHK(hipMemcpyAsync(e->tmp_rec_in.p, in_rec, (size_t)n * sizeof(mvs_patch), hipMemcpyHostToDevice, st));
     }
-    HIPCHK(hipMemsetAsync(e->tmp_i.p, 0, (size_t)n * sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(e->tmp_i.p, 0, (size_t)(n + 1) * sizeof(int32_t), st));
     const DParams p = current_params(e);
     mvsk_probe(p, op, n, e->tmp_rec_in.p, e->tmp_f_in.p, e->tmp_rec_out.p, e->tmp_f_out.p, e->tmp_i.p, st);
     if (out_rec && (op == MVS_PROBE_PREPROCESS || op == MVS_PROBE_REFINE || op == MVS_PROBE_POSTPROCESS))

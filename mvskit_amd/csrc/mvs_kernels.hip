@@ -1,6 +1,7 @@
 // mvs_kernels.hip -- HIP kernels of the MI355X PatchMatch-MVS engine (gfx950, wave64).
 #include <hip/hip_runtime.h>
 #include "mvs_device.cuh"
+#include "mvs_check.cuh"
 #include "mvs_kernels.h"
 
 using namespace mvsdev;
@@ -346,6 +347,13 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
                 if (pre_process(prm, wc, s_scratch, c) == -1) { ++n_f0; continue; }
                 refine_patch(prm, wc, c, k0, k1, k2, k3);
                 if (post_process(prm, wc, s_scratch, s_texs, tstride, c) == -1) { ++n_f1; continue; }
+                if (prm.depth >= 2 && prm.enable_check) {  // Optim::check, optim.cpp:292
+                    __syncthreads();
+                    if (wc.lane < MVS_CAPMAX) s_scratch[wc.lane] = L_id;  // publish the live list of this cell
+                    __syncthreads();
+                    const CheckCtx cx{a.staging, v, cell, L_n, s_scratch};
+                    if (check_patch(prm, wc, cx, c, s_texs, a.error_flag)) { ++n_f1; continue; }
+                }
                 // staging slot for the accepted patch
                 unsigned long long slot64 = 0;
                 if (wc.lane == 0) slot64 = atomicAdd(a.stage_counter, 1ull);
@@ -491,7 +499,11 @@ __global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, co
         refine_patch(prm, wc, c, 0u, 0u, (uint32_t)i, 0u);
         store_cand(out + i, wc, c, 1, (int)i);
     } else if (op == 3) {
-        const int f = post_process(prm, wc, s_scratch, s_texs, tstride, c);
+        int f = post_process(prm, wc, s_scratch, s_texs, tstride, c);
+        if (f == 0 && prm.depth >= 2 && prm.enable_check) {
+            const CheckCtx cx{in, -1, -1, 0, s_scratch};  // no staged ids in a probe (a null pointer here crashes clang 22)
+            if (check_patch(prm, wc, cx, c, s_texs, out_i + n)) f = -1;  // out_i[n]: overflow flag word
+        }
         store_cand(out + i, wc, c, 1, (int)i);
         if (wc.lane == 0) out_i[i] = f;
     } else if (op == 4) {
@@ -542,7 +554,11 @@ void mvsk_map_extract(const DParams& prm, int view, int kind, const unsigned lon
 void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_fill_ncc, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, evals);
 }
-size_t mvsk_sweep_lds_bytes(const DParams& prm) { return (size_t)MVS_LISTCAP * 3 * ((prm.wsz + 3) & ~3) * sizeof(float); }
+size_t mvsk_sweep_lds_bytes(const DParams& prm) {
+    const size_t texs = (size_t)MVS_LISTCAP * 3 * ((prm.wsz + 3) & ~3) * sizeof(float);  // setRefImage textures
+    const size_t chk = (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float);                      // Optim::check hash set + rows
+    return texs > chk ? texs : chk;
+}
 void mvsk_sweep(const DParams& prm, const SweepArgs& a, hipStream_t st) {
     if (a.njobs <= 0) return;
     const int64_t chunk = (a.njobs + 7) / 8;

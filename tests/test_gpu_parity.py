@@ -150,3 +150,54 @@ def test_propagate_two_iterations_matches_oracle(small_multi_scene):
         assert (po["coord"].view(np.uint32) == pe["coord"].view(np.uint32)).all(axis=1).mean() > 0.999
     tot, bad = _maps_close(o, e, sc.nviews)
     assert tot > 2000 and bad == 0
+
+
+def test_check_stage_probe(small_multi_scene):
+    """Optim::check (optim.cpp:300-323: computeGain, findNeighbors, filterQuad) through postProcess at m_depth = 2."""
+    sc = small_multi_scene
+    o, e = _pair(sc, seed=11, enable_check=1)
+    seeds = synth.make_seeds(sc, stride=2, seed=3)
+    o.add_patches(seeds)
+    e.upload_patches(seeds)
+    co, ce = o.propagate(0), e.propagate(0)  # populate the grids (depth 1: no check yet)
+    assert co["patches"] == ce["patches"]
+    o.update_threshold()
+    e.update_threshold()
+    assert o.thresholds()[2] == 2 and e.thresholds()[2] == 2
+    cand = o.patches()[::7][:400]
+    post_rec, _, post_flag = e.probe(engine.PROBE_POSTPROCESS, cand)
+    rejected = passed = 0
+    for j in range(cand.shape[0]):
+        f, r = o.postprocess(cand[j])
+        assert f == post_flag[j], j
+        if f == 0:
+            _cmp_records(post_rec[j], r, f"post+check {j}")
+            np.testing.assert_allclose(post_rec[j]["tmp"], r["tmp"], rtol=REL_TOL, atol=1e-5)  # m_tmp = gain
+            passed += 1
+        else:
+            rejected += 1
+    assert passed > 50
+
+
+def test_three_iterations_with_check(small_multi_scene):
+    """PmMvps::run's loop (pmmvps.cpp:90-110) without Filter::run: m_depth 1, 2, 3 -- Optim::check active from iteration 1."""
+    sc = small_multi_scene
+    o, e = _pair(sc, seed=13, enable_check=1)
+    seeds = synth.make_seeds(sc, stride=4, seed=17)
+    o.add_patches(seeds)
+    e.upload_patches(seeds)
+    for it in range(3):
+        co, ce = o.propagate(it), e.propagate(it)
+        for k in ("candidates", "prefiltered", "patches", "fail0", "fail1", "inserted", "replaced", "evals", "view_evals", "trimmed"):
+            assert co[k] == ce[k], (it, k, co, ce)
+        o.update_threshold()
+        e.update_threshold()
+    po, pe = o.patches(), e.patches()
+    assert po.shape == pe.shape
+    np.testing.assert_array_equal(po["images"], pe["images"])
+    np.testing.assert_array_equal(po["vimages"], pe["vimages"])
+    np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+    np.testing.assert_allclose(pe["normal"], po["normal"], rtol=0, atol=REL_TOL)
+    np.testing.assert_allclose(pe["tmp"], po["tmp"], rtol=REL_TOL, atol=1e-5)
+    tot, bad = _maps_close(o, e, sc.nviews)
+    assert tot > 2000 and bad == 0
