@@ -61,16 +61,20 @@ DEV int is_neighbor_radius(const DParams& prm, const PGeo& l, const PGeo& r, flo
     return ftmp < thr ? 1 : 0;
 }
 
-// list of (kind, view, cell): kind 0 = m_pgrids, 1 = m_vpgrids.  Returns [b, e) into ids, or the live list.
-DEV void cell_span(const DParams& prm, const CheckCtx& cx, int kind, int view, int cell, const int*& ids, int& n, bool& live) {
-    live = kind == 0 && view == cx.live_view && cell == cx.live_cell;
-    if (live) { ids = cx.live_ids; n = cx.live_n; return; }
-    const DView* vw = prm.views + view;
-    const int g = vw->cell_base + cell;
-    const int* st = kind == 0 ? prm.csr_start : prm.vcsr_start;
-    const int* id = kind == 0 ? prm.csr_ids : prm.vcsr_ids;
-    ids = id + st[g];
-    n = st[g + 1] - st[g];
+// List of (kind, view, cell): kind 0 = m_pgrids, 1 = m_vpgrids.  Snapshot lists are contiguous CellEntry streams
+// (alive entries only); the destination cell being processed is read through its live id list instead.
+struct ListRef { const CellEntry* fat; int n; bool live; };
+DEV ListRef cell_span(const DParams& prm, const CheckCtx& cx, int kind, int view, int cell) {
+    if (kind == 0 && view == cx.live_view && cell == cx.live_cell) return {nullptr, cx.live_n, true};
+    const int g = (prm.views + view)->cell_base + cell;
+    if (kind == 0) return {prm.csr_fat + prm.csr_start[g], prm.csr_cnt[g], false};
+    return {prm.vcsr_fat + prm.vcsr_start[g], prm.vcsr_cnt[g], false};
+}
+DEV PGeo entry_geo(const DParams& prm, const CheckCtx& cx, const ListRef& l, int j, int& id) {
+    if (l.live) { id = cx.live_ids[j]; return load_geo(patch_ptr(prm, cx, id)); }
+    const CellEntry e = l.fat[j];
+    id = e.id;
+    return {{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
 }
 
 // Filter::computeGain, filter.cpp:108-146
@@ -80,13 +84,10 @@ DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     float maxp = 0.0f;
     if (wc.lane < c.nimg) {
         const int v = c.img;
-        const int cell = c.gy * (prm.views + v)->gw + c.gx;
-        const int* ids; int n; bool live;
-        cell_span(prm, cx, 0, v, cell, ids, n, live);
-        for (int j = 0; j < n; ++j) {
-            const DPatch* q = patch_ptr(prm, cx, ids[j]);
-            if (!live && !(q->flags & 1)) continue;
-            const PGeo g = load_geo(q);
+        const ListRef l = cell_span(prm, cx, 0, v, c.gy * (prm.views + v)->gw + c.gx);
+        for (int j = 0; j < l.n; ++j) {
+            int id;
+            const PGeo g = entry_geo(prm, cx, l, j, id);
             if (!is_neighbor(prm, me, g, prm.neighborThreshold1)) maxp = fmaxf(maxp, g.ncc - prm.nccThreshold);
         }
     }
@@ -96,13 +97,10 @@ DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
         const int v = c.vimg;
         const DView* vw = prm.views + v;
         const float pdepth = dot4(ld4(vw->oaxis), c.coord);
-        const int cell = c.vgy * vw->gw + c.vgx;
-        const int* ids; int n; bool live;
-        cell_span(prm, cx, 0, v, cell, ids, n, live);
-        for (int j = 0; j < n; ++j) {
-            const DPatch* q = patch_ptr(prm, cx, ids[j]);
-            if (!live && !(q->flags & 1)) continue;
-            const PGeo g = load_geo(q);
+        const ListRef l = cell_span(prm, cx, 0, v, c.vgy * vw->gw + c.vgx);
+        for (int j = 0; j < l.n; ++j) {
+            int id;
+            const PGeo g = entry_geo(prm, cx, l, j, id);
             const float bdepth = dot4(ld4(vw->oaxis), g.coord);
             if (pdepth < bdepth && !is_neighbor(prm, me, g, prm.neighborThreshold1)) maxp = fmaxf(maxp, g.ncc - prm.nccThreshold);
         }
@@ -154,13 +152,11 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
             if (!(yt < 0 || vw->gh <= yt || xt < 0 || vw->gw <= xt)) {
                 const int cell = yt * vw->gw + xt;
                 for (int kind = 0; kind < 2; ++kind) {
-                    const int* ids; int n; bool live;
-                    cell_span(prm, cx, kind, v, cell, ids, n, live);
-                    for (int j = 0; j < n; ++j) {
-                        const int id = ids[j];
-                        const DPatch* q = patch_ptr(prm, cx, id);
-                        if (!live && !(q->flags & 1)) continue;
-                        if (!is_neighbor_radius(prm, me, load_geo(q), unit, thr, radius)) continue;
+                    const ListRef l = cell_span(prm, cx, kind, v, cell);
+                    for (int j = 0; j < l.n; ++j) {
+                        int id;
+                        const PGeo g = entry_geo(prm, cx, l, j, id);
+                        if (!is_neighbor_radius(prm, me, g, unit, thr, radius)) continue;
                         unsigned h = (mix32((uint32_t)id)) & (MVS_HASH_CAP - 1);
                         for (int probe = 0; probe < MVS_HASH_CAP; ++probe) {
                             const int old = atomicCAS(&table[h], -1, id);
@@ -173,7 +169,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
         }
     }
     __syncthreads();
-    // compact the set to the front of the table (through a second region: the upper half is not needed once read)
+    // compact the set to the front of the table
     int count = 0;
     int mine[MVS_HASH_CAP / 64];
 #pragma unroll

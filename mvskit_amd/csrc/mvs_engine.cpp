@@ -63,6 +63,8 @@ struct mvs_engine {
     bool ncc_dirty = false;
     // index
     DevBuf<int32_t> cnt, start, cursor, ids, vcnt, vstart, vcursor, vids, scan_tmp;
+    DevBuf<CellEntry> fat, vfat;
+    DevBuf<int32_t> cnt_alive, vcnt_alive;
     DevBuf<unsigned long long> dpgrid, best;
     bool index_valid = false;
     // sweep / staging
@@ -181,8 +183,8 @@ DParams current_params(mvs_engine* e) {
     p.pool = e->pool.p;
     p.pool_n = e->pool_n;
     p.total_cells = e->total_cells;
-    p.csr_start = e->start.p; p.csr_ids = e->ids.p;
-    p.vcsr_start = e->vstart.p; p.vcsr_ids = e->vids.p;
+    p.csr_start = e->start.p; p.csr_cnt = e->cnt_alive.p; p.csr_fat = e->fat.p;
+    p.vcsr_start = e->vstart.p; p.vcsr_cnt = e->vcnt_alive.p; p.vcsr_fat = e->vfat.p;
     p.dpgrid = e->dpgrid.p;
     return p;
 }
@@ -210,7 +212,8 @@ int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
     if (vg) HIPCHK(hipMemcpyAsync(&vtot, e->vstart.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (int r = e->ids.ensure(tot + 16)) return r;
-    if (vg) if (int r = e->vids.ensure(vtot + 16)) return r;
+    if (int r = e->fat.ensure(tot + 16)) return r;
+    if (vg) { if (int r = e->vids.ensure(vtot + 16)) return r; if (int r = e->vfat.ensure(vtot + 16)) return r; }
     p = current_params(e);
     HIPCHK(hipMemsetAsync(e->cursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
     if (vg) HIPCHK(hipMemsetAsync(e->vcursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
@@ -218,6 +221,8 @@ int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
     HIPCHK(hipMemsetAsync(e->misc.p + 3, 0, sizeof(unsigned long long), st));
     mvsk_index_sort_trim(p, e->start.p, e->ids.p, 1, e->misc.p + 3, st);
     if (vg) mvsk_index_sort_trim(p, e->vstart.p, e->vids.p, 0, e->misc.p + 3, st);
+    mvsk_index_finalize(p, e->start.p, e->ids.p, e->fat.p, e->cnt_alive.p, st);
+    if (vg) mvsk_index_finalize(p, e->vstart.p, e->vids.p, e->vfat.p, e->vcnt_alive.p, st);
     HIPCHK(hipMemsetAsync(e->dpgrid.p, 0xff, (size_t)nc * sizeof(unsigned long long), st));
     mvsk_depth_maps(p, e->dpgrid.p, st);
     if (trimmed_out) {
@@ -333,7 +338,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     free_views(e);
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
-    e->vcursor.release(); e->vids.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
+    e->vcursor.release(); e->vids.release(); e->fat.release(); e->vfat.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
     e->tmp_rec_in.release(); e->tmp_rec_out.release(); e->tmp_f_in.release(); e->tmp_f_out.release(); e->tmp_i.release(); e->tmp_bytes.release();
@@ -399,7 +404,7 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
     HIPCHK(hipMemcpyAsync(e->dviews.p, e->hviews.data(), sizeof(DView) * nviews, hipMemcpyHostToDevice, st));
     const int64_t nc = e->total_cells;
     if (e->cnt.ensure(nc + 2) || e->start.ensure(nc + 2) || e->cursor.ensure(nc + 2) || e->vcnt.ensure(nc + 2) || e->vstart.ensure(nc + 2) ||
-        e->vcursor.ensure(nc + 2) || e->dpgrid.ensure(nc + 2) || e->best.ensure(nc + 2))
+        e->vcursor.ensure(nc + 2) || e->dpgrid.ensure(nc + 2) || e->best.ensure(nc + 2) || e->cnt_alive.ensure(nc + 2) || e->vcnt_alive.ensure(nc + 2))
         return MVS_ERR_HIP;
     const int64_t pool_cap = e->cfg.max_patches > 0 ? e->cfg.max_patches : 6 * nc;
     if (e->pool.ensure(pool_cap) || e->pool_alt.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;

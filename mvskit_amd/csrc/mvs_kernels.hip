@@ -176,6 +176,27 @@ __global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start
         }
     }
 }
+// After the trim: every list is compacted to its alive entries (order kept) and written out "fat".
+__global__ void k_index_finalize(DParams prm, const int32_t* __restrict__ start, const int32_t* __restrict__ ids, CellEntry* __restrict__ fat,
+                                 int32_t* __restrict__ cnt_alive) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= prm.total_cells) return;
+    const int b = start[g], e = start[g + 1];
+    int n = 0;
+    for (int k = b; k < e; ++k) {
+        const int id = ids[k];
+        const DPatch* p = prm.pool + id;
+        if (!(p->flags & 1)) continue;
+        CellEntry ce;
+        ce.id = id; ce.ncc = p->ncc;
+        ce.coord[0] = p->coord[0]; ce.coord[1] = p->coord[1]; ce.coord[2] = p->coord[2];
+        ce.normal[0] = p->normal[0]; ce.normal[1] = p->normal[1]; ce.normal[2] = p->normal[2];
+        ce.dscale = p->dscale; ce.ref = p->images[0]; ce.pad[0] = 0; ce.pad[1] = 0;
+        fat[b + n] = ce;
+        ++n;
+    }
+    cnt_alive[g] = n;
+}
 DEV uint32_t sortable_f32(float f) {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -282,7 +303,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
     for (int k = 0; k < 2; ++k) {
         if (sxs[k] < 0 || gw <= sxs[k] || sys[k] < 0 || gh <= sys[k]) continue;
         const int g = vw->cell_base + sys[k] * gw + sxs[k];
-        has |= prm.csr_start[g + 1] > prm.csr_start[g];
+        has |= prm.csr_cnt[g] > 0;
     }
     if (!has) return;
 
@@ -294,14 +315,9 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
     int L_n = 0;
     {
         const int g = vw->cell_base + cell;
-        const int b = prm.csr_start[g], e = prm.csr_start[g + 1];
-        for (int k = b; k < e; ++k) {
-            const int id = prm.csr_ids[k];
-            const DPatch* p = prm.pool + id;
-            if (!(p->flags & 1)) continue;
-            if (wc.lane == L_n) { L_id = id; L_ncc = p->ncc; }
-            ++L_n;
-        }
+        const CellEntry* fe = prm.csr_fat + prm.csr_start[g];
+        L_n = min(prm.csr_cnt[g], MVS_CAPMAX);
+        if (wc.lane < L_n) { L_id = fe[wc.lane].id; L_ncc = fe[wc.lane].ncc; }
     }
     int ns = 0;  // staged records of this job
     const float icx = (float)(prm.csize * (2 * cx + 1) - 1) / 2.0f, icy = (float)(prm.csize * (2 * cy + 1) - 1) / 2.0f;
@@ -309,14 +325,11 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
     for (int sidx = 0; sidx < 2; ++sidx) {
         if (sxs[sidx] < 0 || gw <= sxs[sidx] || sys[sidx] < 0 || gh <= sys[sidx]) continue;
         const int g = vw->cell_base + sys[sidx] * gw + sxs[sidx];
-        const int sb = prm.csr_start[g], se = prm.csr_start[g + 1];
-        int nalive = 0;
-        for (int k = sb; k < se; ++k) {
-            const int sid = prm.csr_ids[k];
-            const DPatch* sp = prm.pool + sid;
-            if (!(sp->flags & 1)) continue;
-            const int n = nalive++;
-            if (sp->images[0] != v) continue;
+        const CellEntry* se = prm.csr_fat + prm.csr_start[g];
+        const int sn = prm.csr_cnt[g];
+        for (int n = 0; n < sn; ++n) {
+            if (se[n].ref != v) continue;
+            const DPatch* sp = prm.pool + se[n].id;
             const int srcslot = sidx * prm.cap + n;
             // ---- Propagate::propagatePatch, propagate.cpp:153-213
             for (int it = 0; it < prm.max_propag; ++it) {
@@ -540,6 +553,9 @@ void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, 
 }
 void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, int32_t* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
     hipLaunchKernelGGL(k_index_sort_trim, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, do_trim, trimmed);
+}
+void mvsk_index_finalize(const DParams& prm, const int32_t* start, const int32_t* ids, CellEntry* fat, int32_t* cnt_alive, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, fat, cnt_alive);
 }
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, hipStream_t st) {
     const int64_t n = prm.pool_n * prm.nviews;

@@ -21,6 +21,20 @@ struct DPatch {
 };
 static_assert(sizeof(DPatch) == 128, "record is 128 bytes");
 
+// Entry of a cell list in the per-pass index: the patch id plus the fields the list consumers need (sort key,
+// reference view, and the geometry of PmMvps::isNeighbor*), so that walking a list is one contiguous stream
+// instead of a dependent load into the pool per entry.  48 bytes.
+struct CellEntry {
+    int32_t id;
+    float ncc;
+    float coord[3];
+    float normal[3];
+    float dscale;
+    int32_t ref;
+    int32_t pad[2];
+};
+static_assert(sizeof(CellEntry) == 48, "cell entry is 48 bytes");
+
 // One view resident in HBM: camera (image/camera.cpp:65-100), Optim axes (optim.cpp:43-65), pyramid
 // (image/image.cpp:245-315) as RGBA8 texels (one 32-bit load per texel), mask at m_level, grid size.
 struct DView {
@@ -53,10 +67,13 @@ struct DParams {
     DPatch* pool;
     int64_t pool_n;
     // index (rebuilt every pass): per concatenated cell [start, start+cnt) into csr_ids, sorted (ncc desc, id asc)
+    // cell g: entries csr_fat[csr_start[g] .. + csr_cnt[g]) -- alive patches only, sorted (ncc desc, id asc)
     const int32_t* csr_start;
-    const int32_t* csr_ids;
+    const int32_t* csr_cnt;
+    const CellEntry* csr_fat;
     const int32_t* vcsr_start;
-    const int32_t* vcsr_ids;
+    const int32_t* vcsr_cnt;
+    const CellEntry* vcsr_fat;
     const unsigned long long* dpgrid;  // (sortable depth << 32 | id), ~0ull = m_MAXDEPTH
 };
 

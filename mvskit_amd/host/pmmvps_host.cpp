@@ -315,7 +315,7 @@ int PmMvps::createEngine(float maxAngle, float quad) {
     cfg.minImageNum = m_minImageNumThreshold; cfg.nccThreshold = m_nccThreshold;
     cfg.maxAngleThreshold = maxAngle; cfg.quadThreshold = quad;
     cfg.depth = 0; cfg.seed = m_seed; cfg.refine_steps = m_refineSteps;
-    cfg.enable_check = 0;  // Optim::check (m_depth >= 2) is not in the engine yet
+    cfg.enable_check = 1;  // Optim::check from m_depth >= 2 (optim.cpp:292)
     int r = mvs_engine_create(&cfg, &m_engine);
     if (r != 0) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
     vector<mvs_view_desc> views(m_nimages);

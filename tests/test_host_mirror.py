@@ -90,7 +90,7 @@ def test_pmmvps_run_matches_oracle(host, small_plane_scene):
     sc = small_plane_scene
     seeds = synth.make_seeds(sc, stride=4, seed=21)
     iters = 2
-    o = ob.Oracle(sc.nviews, level=0, minImageNum=2, enable_check=0, seed=9, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64, nthreads=8,
+    o = ob.Oracle(sc.nviews, level=0, minImageNum=2, enable_check=1, seed=9, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64, nthreads=8,
                   depth=1)
     o.set_scene(sc)
     o.add_patches(seeds)
