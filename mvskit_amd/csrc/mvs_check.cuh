@@ -154,15 +154,21 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
                 for (int kind = 0; kind < 2; ++kind) {
                     const ListRef l = cell_span(prm, cx, kind, v, cell);
                     for (int j = 0; j < l.n; ++j) {
-                        int id;
-                        const PGeo g = entry_geo(prm, cx, l, j, id);
-                        if (!is_neighbor_radius(prm, me, g, unit, thr, radius)) continue;
+                        // a patch shows up in the cells of several views: the set remembers every id it has seen
+                        // (id = tested and accepted, -2 - id = tested and rejected), the predicate runs once per id
+                        const int id = l.live ? cx.live_ids[j] : l.fat[j].id;
                         unsigned h = (mix32((uint32_t)id)) & (MVS_HASH_CAP - 1);
+                        bool fresh = false;
                         for (int probe = 0; probe < MVS_HASH_CAP; ++probe) {
                             const int old = atomicCAS(&table[h], -1, id);
-                            if (old == -1 || old == id) break;
+                            if (old == -1) { fresh = true; break; }
+                            if (old == id || old == -2 - id) break;
                             h = (h + 1) & (MVS_HASH_CAP - 1);
                         }
+                        if (!fresh) continue;
+                        int id2;
+                        const PGeo g = entry_geo(prm, cx, l, j, id2);
+                        if (!is_neighbor_radius(prm, me, g, unit, thr, radius)) table[h] = -2 - id;
                     }
                 }
             }
@@ -177,7 +183,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < MVS_HASH_CAP / 64; ++k) {
-        const bool has = mine[k] != -1;
+        const bool has = mine[k] >= 0;
         const unsigned long long m = ballot(has);
         if (has) table[count + __popcll(m & ((1ull << wc.lane) - 1ull))] = mine[k];
         count += __popcll(m);
@@ -214,44 +220,63 @@ DEV void ortho(F4 z, F4& x, F4& y) {
     y = {z.y * x.z - z.z * x.y, z.z * x.x - z.x * x.z, z.x * x.y - z.y * x.x, 0.0f};
 }
 
-// Filter::filterQuad, filter.cpp:329-392.  nb = sorted ids in LDS (n of them); rows = LDS scratch of 3*n floats
-// (fx, fy, fz per neighbour; the five regressors fx^2, fy^2, fx*fy, fx, fy are re-formed from them).
-DEV float quad_term(int k, float fx, float fy, float fz) {
-    return k == 0 ? fx * fx : k == 1 ? fy * fy : k == 2 ? fx * fy : k == 3 ? fx : k == 4 ? fy : fz;
+// double-precision wave butterfly, same pairing order as wave_sum
+template <int CTRL, int RM> DEV double dpp_d(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, RM, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, RM, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
 }
+DEV double wave_sum_f64(double x) {
+    x = x + dpp_d<0xB1, 0xf>(x);
+    x = x + dpp_d<0x4E, 0xf>(x);
+    x = x + dpp_d<0x141, 0xf>(x);
+    x = x + dpp_d<0x140, 0xf>(x);
+    x = x + dpp_d<0x142, 0xa>(x);
+    x = x + dpp_d<0x143, 0xc>(x);
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
+// Filter::filterQuad, filter.cpp:329-392.  nb = sorted ids in LDS (n of them); rows = LDS scratch of 3*n floats
+// (fx, fy, fz per neighbour).  The three sums over the neighbours (mean distance, normal equations, residual) are
+// lane-strided partial sums (lane l takes neighbours l, l+64, ...) followed by a wave butterfly.
 DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, const int* nb, int n, float* rows) {
     F4 xdir, ydir;
     ortho(c.normal, xdir, ydir);
-    // h = mean distance, summed in neighbour order
-    for (int t = wc.lane; t < n; t += 64) rows[t] = norm4(sub4(ld4(patch_ptr(prm, cx, nb[t])->coord), c.coord));
-    __syncthreads();
-    float h = 0.0f;
-    for (int t = 0; t < n; ++t) h += rows[t];
+    float hp = 0.0f;
+    for (int t = wc.lane; t < n; t += 64) hp += norm4(sub4(ld4(patch_ptr(prm, cx, nb[t])->coord), c.coord));
+    float h = wave_sum(hp);
     h /= (float)n;
-    __syncthreads();
+    // Filter::lls: M = [A^T A | A^T b] with A = (fx^2, fy^2, fx fy, fx, fy), b = fz; 15 + 5 distinct sums, in double
+    double acc[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) acc[k] = 0.0;
     for (int t = wc.lane; t < n; t += 64) {
         const F4 diff = sub4(ld4(patch_ptr(prm, cx, nb[t])->coord), c.coord);
-        rows[3 * t + 0] = dot4(diff, xdir) / h; rows[3 * t + 1] = dot4(diff, ydir) / h; rows[3 * t + 2] = dot4(diff, c.normal);
-    }
-    __syncthreads();
-    // Filter::lls: M[i][j] += A[r][i] * A[r][j], M[i][5] += A[r][i] * b[r]; lane 6*i + j holds M[i][j]
-    double macc = 0.0;
-    const int mi = wc.lane / 6, mj = wc.lane % 6;
-    if (wc.lane < 30) {
-        for (int r = 0; r < n; ++r) {
-            const float fx = rows[3 * r], fy = rows[3 * r + 1], fz = rows[3 * r + 2];
-            macc += (double)quad_term(mi, fx, fy, fz) * (double)quad_term(mj, fx, fy, fz);
-        }
+        const float fx = dot4(diff, xdir) / h, fy = dot4(diff, ydir) / h, fz = dot4(diff, c.normal);
+        rows[3 * t + 0] = fx; rows[3 * t + 1] = fy; rows[3 * t + 2] = fz;
+        const float a[6] = {fx * fx, fy * fy, fx * fy, fx, fy, fz};
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                if (j == 5) acc[15 + i] += (double)a[i] * (double)a[5];
+                else acc[k++] += (double)a[i] * (double)a[j];
+            }
     }
     double M[5][6];
+    {
+        int k = 0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < 5; ++i) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(macc) & 0xffffffffll), 6 * i + j);
-            const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(macc) >> 32), 6 * i + j);
-            M[i][j] = __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+            for (int j = i; j < 5; ++j) { const double v = wave_sum_f64(acc[k++]); M[i][j] = v; M[j][i] = v; }
+            M[i][5] = wave_sum_f64(acc[15 + i]);
         }
+    }
     double x[5] = {0, 0, 0, 0, 0};
     bool solved = true;
 #pragma unroll
@@ -283,13 +308,14 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
     if (solved) {
 #pragma unroll
         for (int r = 4; r >= 0; --r) {
-            double acc = M[r][5];
+            double a2 = M[r][5];
 #pragma unroll
-            for (int k = r + 1; k < 5; ++k) acc -= M[r][k] * x[k];
-            x[r] = acc / M[r][r];
+            for (int k = r + 1; k < 5; ++k) a2 -= M[r][k] * x[k];
+            x[r] = a2 / M[r][r];
         }
     }
-    const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3], x4 = (float)x[4];
+    const float x0 = solved ? (float)x[0] : 0.0f, x1 = solved ? (float)x[1] : 0.0f, x2 = solved ? (float)x[2] : 0.0f,
+                x3 = solved ? (float)x[3] : 0.0f, x4 = solved ? (float)x[4] : 0.0f;
     const int inum = min(prm.tau, c.nimg);
     float unit = 0.0f;
     {
@@ -298,15 +324,13 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
         for (int i = 0; i < inum; ++i) unit += rlf(gu, i);
         unit /= (float)inum;
     }
-    __syncthreads();
+    float rp = 0.0f;
     for (int t = wc.lane; t < n; t += 64) {
         const float fx = rows[3 * t], fy = rows[3 * t + 1], fz = rows[3 * t + 2];
         const float res = x0 * (fx * fx) + x1 * (fy * fy) + x2 * (fx * fy) + x3 * fx + x4 * fy - fz;
-        rows[3 * t] = fabsf(res) / unit;
+        rp += fabsf(res) / unit;
     }
-    __syncthreads();
-    float residual = 0.0f;
-    for (int t = 0; t < n; ++t) residual += rows[3 * t];
+    float residual = wave_sum(rp);
     residual /= (float)(n - 5);
     return residual < prm.quadThreshold ? 0 : 1;
 }
@@ -314,11 +338,16 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
 // Optim::check, optim.cpp:300-323.  lds: MVS_CHECK_LDS_FLOATS floats (the kernel's dynamic LDS region).
 // Returns 1 when the patch is rejected.  Neighbours beyond MVS_ROW_CAP are ignored (and flagged in *overflow).
 DEV int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, Cand& c, float* lds, int* overflow) {
+#ifndef MVS_CHECK_STAGES
+#define MVS_CHECK_STAGES 3  // timing experiments only: 1 = gain, 2 = + neighbours, 3 = everything
+#endif
     const float gain = compute_gain(prm, wc, cx, c);
     c.tmp = gain;
     if (gain < 0.0f) { c.nimg = 0; return 1; }
+    if (MVS_CHECK_STAGES < 2) return 0;
     int* table = reinterpret_cast<int*>(lds);
     int n = find_neighbors(prm, wc, cx, c, table, 4.0f, 2);
+    if (MVS_CHECK_STAGES < 3) return 0;
     if (6 < n) {
         if (n > MVS_ROW_CAP) { n = MVS_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }
         if (filter_quad(prm, wc, cx, c, table, n, lds + MVS_HASH_CAP)) { c.nimg = 0; return 1; }

@@ -1025,15 +1025,45 @@ void ortho(const V4& z, V4& x, V4& y) {
     y = {z.y * x.z - z.z * x.y, z.z * x.x - z.x * x.z, z.x * x.y - z.y * x.x, 0};
 }
 
-/* Filter::lls, filter.cpp:411-430: least squares n x 5 (Eigen jacobiSvd there; normal equations
- * with partial-pivot Gaussian elimination in double here). */
-bool lls5(const std::vector<std::array<float, 5>>& A, const std::vector<float>& b, double* x) {
-    double M[5][6] = {{0}};
-    for (size_t r = 0; r < A.size(); ++r)
-        for (int i = 0; i < 5; ++i) {
-            for (int j = 0; j < 5; ++j) M[i][j] += (double)A[r][i] * (double)A[r][j];
-            M[i][5] += (double)A[r][i] * (double)b[r];
+/* Sums over the n neighbours of Filter::filterQuad.  SEQ: the reference's order.  TREE64 (engine): lane l adds the
+ * elements l, l + 64, l + 128, ... in that order, then the 64 partial sums go through the wave butterfly. */
+float reduce_n_f32(const Scene& s, const std::vector<float>& a) {
+    const int n = (int)a.size();
+    if (s.cfg.sum_mode != ORC_SUM_TREE64) { float t = 0.0f; for (int i = 0; i < n; ++i) t += a[i]; return t; }
+    float part[64];
+    for (int l = 0; l < 64; ++l) { part[l] = 0.0f; for (int t = l; t < n; t += 64) part[l] += a[t]; }
+    return reduce_tree64(part);
+}
+double reduce_tree64_f64(const double* a) {
+    double b[64], t[64];
+    for (int i = 0; i < 64; ++i) b[i] = a[i];
+    for (int off = 1; off < 64; off <<= 1) {
+        for (int i = 0; i < 64; ++i) t[i] = b[i] + b[i ^ off];
+        for (int i = 0; i < 64; ++i) b[i] = t[i];
+    }
+    return b[0];
+}
+
+/* Filter::lls, filter.cpp:411-430: least squares n x 5 (Eigen jacobiSvd there; normal equations with partial-pivot
+ * Gaussian elimination in double here).  build_normal_equations forms M = [A^T A | A^T b]; solve5 solves it. */
+void build_normal_equations(const Scene& s, const std::vector<std::array<float, 5>>& A, const std::vector<float>& b, double M[5][6]) {
+    const int n = (int)A.size();
+    for (int i = 0; i < 5; ++i) for (int j = 0; j < 6; ++j) {
+        if (s.cfg.sum_mode != ORC_SUM_TREE64) {
+            double acc = 0.0;
+            for (int r = 0; r < n; ++r) acc += (double)A[r][i] * (double)(j < 5 ? A[r][j] : b[r]);
+            M[i][j] = acc;
+        } else {
+            double part[64];
+            for (int l = 0; l < 64; ++l) {
+                part[l] = 0.0;
+                for (int r = l; r < n; r += 64) part[l] += (double)A[r][i] * (double)(j < 5 ? A[r][j] : b[r]);
+            }
+            M[i][j] = reduce_tree64_f64(part);
         }
+    }
+}
+bool solve5(double M[5][6], double* x) {
     for (int c = 0; c < 5; ++c) {
         int piv = c;
         for (int r = c + 1; r < 5; ++r) if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
@@ -1057,8 +1087,9 @@ int filter_quad(const Scene& s, const Patch& p, const std::vector<int>& nb, cons
     V4 xdir, ydir;
     ortho(p.normal, xdir, ydir);
     const int n = (int)nb.size();
-    float h = 0.0f;
-    for (int i = 0; i < n; ++i) h += norm4(sub4(get_patch(s, nb[i], ctx).coord, p.coord));
+    std::vector<float> dist(n);
+    for (int i = 0; i < n; ++i) dist[i] = norm4(sub4(get_patch(s, nb[i], ctx).coord, p.coord));
+    float h = reduce_n_f32(s, dist);
     h /= n;
     std::vector<std::array<float, 5>> A(n);
     std::vector<float> b(n), fxs(n), fys(n), fzs(n);
@@ -1071,18 +1102,21 @@ int filter_quad(const Scene& s, const Patch& p, const std::vector<int>& nb, cons
         b[i] = fzs[i];
     }
     double xd[5] = {0, 0, 0, 0, 0};
-    lls5(A, b, xd);
+    double M[5][6];
+    build_normal_equations(s, A, b, M);
+    if (!solve5(M, xd)) for (double& v : xd) v = 0.0;
     float x[5];
     for (int i = 0; i < 5; ++i) x[i] = (float)xd[i];
     const int inum = std::min(s.tau, p.nimg);
     float unit = 0.0f;
     for (int i = 0; i < inum; ++i) unit += get_unit(s, p.img[i], p.coord);
     unit /= inum;
-    float residual = 0.0f;
+    std::vector<float> rs(n);
     for (int i = 0; i < n; ++i) {
         const float res = x[0] * (fxs[i] * fxs[i]) + x[1] * (fys[i] * fys[i]) + x[2] * (fxs[i] * fys[i]) + x[3] * fxs[i] + x[4] * fys[i] - fzs[i];
-        residual += fabsf(res) / unit;
+        rs[i] = fabsf(res) / unit;
     }
+    float residual = reduce_n_f32(s, rs);
     residual /= (n - 5);
     return residual < s.cfg.quadThreshold ? 0 : 1;
 }
