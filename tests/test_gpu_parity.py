@@ -201,3 +201,44 @@ def test_three_iterations_with_check(small_multi_scene):
     np.testing.assert_allclose(pe["tmp"], po["tmp"], rtol=REL_TOL, atol=1e-5)
     tot, bad = _maps_close(o, e, sc.nviews)
     assert tot > 2000 and bad == 0
+
+
+def test_device_exchange_world1_equals_local_commit(small_multi_scene):
+    """mvskit_amd.dist.DeviceExchange (export to device buffers, RCCL all-gather, commit of the union) with one rank must
+    give exactly the pool that the in-engine commit gives."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from mvskit_amd.dist import DeviceExchange
+
+    sc = small_multi_scene
+    seeds = synth.make_seeds(sc, stride=4, seed=23)
+    kw = dict(level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=5)
+    a = engine.Engine(sc.nviews, **kw)
+    b = engine.Engine(sc.nviews, **kw)
+    for e in (a, b):
+        e.set_scene(sc)
+        e.upload_patches(seeds)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        ex = DeviceExchange(torch.device("cuda", 0))
+        for it in range(2):
+            ca = a.propagate(it)
+            cb = ex.propagate(b, it)
+            assert ca == cb, (it, ca, cb)
+            a.update_threshold()
+            b.update_threshold()
+        pa, pb = a.patches(), b.patches()
+        assert pa.shape == pb.shape
+        for f in ("coord", "normal", "ncc", "dscale", "ascale", "tmp", "nimages", "images", "nvimages", "vimages"):
+            np.testing.assert_array_equal(pa[f], pb[f], err_msg=f)
+    finally:
+        if created:
+            dist.destroy_process_group()
