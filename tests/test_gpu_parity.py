@@ -242,3 +242,73 @@ def test_device_exchange_world1_equals_local_commit(small_multi_scene):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _one_iteration_matches(sc, seeds, masks=None, **kw):
+    o, e = _pair(sc, **kw)
+    if masks is not None:
+        o.set_scene(sc, masks=masks)
+        e.set_scene(sc, masks=masks)
+    o.add_patches(seeds)
+    e.upload_patches(seeds)
+    co, ce = o.propagate(0), e.propagate(0)
+    assert co == ce, (co, ce)
+    po, pe = o.patches(), e.patches()
+    assert po.shape == pe.shape
+    np.testing.assert_array_equal(po["images"], pe["images"])
+    np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+    np.testing.assert_allclose(pe["normal"], po["normal"], rtol=0, atol=REL_TOL)
+    return co
+
+
+def test_variant_level1(small_multi_scene):
+    # Option::m_level = 1 (the reference's default, option.cpp:20): grids and projections one pyramid level down
+    seeds = synth.make_seeds(small_multi_scene, level=1, stride=3, seed=2)
+    c = _one_iteration_matches(small_multi_scene, seeds, level=1, seed=3)
+    assert c["patches"] > 300
+
+
+def test_variant_wsize5_csize1(small_plane_scene):
+    # 5x5 windows (25 sample lanes) and csize 1 (MAX_NUM_OF_PATCHES = 2)
+    seeds = synth.make_seeds(small_plane_scene, csize=1, stride=6, seed=4)
+    c = _one_iteration_matches(small_plane_scene, seeds, minImageNum=2, wsize=5, csize=1, seed=9)
+    assert c["patches"] > 300
+
+
+def test_variant_csize3(small_plane_scene):
+    seeds = synth.make_seeds(small_plane_scene, csize=3, stride=2, seed=6)
+    c = _one_iteration_matches(small_plane_scene, seeds, minImageNum=2, csize=3, seed=1)
+    assert c["patches"] > 300
+
+
+def test_variant_masks(small_plane_scene):
+    # PhotoSet::getMask (photoSet.cpp:223-233): a patch that projects onto a zero mask pixel of any view is dropped
+    sc = small_plane_scene
+    masks = np.full((sc.nviews, sc.H, sc.W), 255, np.uint8)
+    masks[:, :, : sc.W // 3] = 0
+    masks[1, sc.H // 2:, :] = 90  # < 128: binarised to 0 (image.cpp:170-177)
+    seeds = synth.make_seeds(sc, stride=4, seed=8)
+    c = _one_iteration_matches(sc, seeds, masks=masks, minImageNum=2, seed=2)
+    assert c["fail1"] > 50 and c["inserted"] > 50
+
+
+def test_two_view_config(small_plane_scene):
+    # BASELINE.json configs[0]: 2 views, minImageNum 2, one PatchMatch iteration
+    sc = synth.Scene(W=small_plane_scene.W, H=small_plane_scene.H, P=small_plane_scene.P[[0, 2]], images=small_plane_scene.images[[0, 2]],
+                     centers=small_plane_scene.centers[[0, 2]], points=small_plane_scene.points[[0, 2]], normals=small_plane_scene.normals[[0, 2]],
+                     meta=small_plane_scene.meta)
+    seeds = synth.make_seeds(sc, stride=4, seed=12)
+    c = _one_iteration_matches(sc, seeds, minImageNum=2, seed=4)
+    assert c["patches"] > 300 and c["inserted"] > 100
+
+
+def test_empty_pool_and_reupload(small_plane_scene):
+    o, e = _pair(small_plane_scene, minImageNum=2)
+    assert e.propagate(0)["patches"] == 0 and e.num_patches() == 0
+    seeds = synth.make_seeds(small_plane_scene, stride=8, seed=1)
+    ragged = seeds.copy()
+    ragged["nimages"][::5] = 0          # records without images are dropped (patch_manager.cpp:457-459)
+    e.upload_patches(ragged)
+    assert e.num_patches() == int((ragged["nimages"] > 0).sum())
+    e.clear_patches()
+    assert e.num_patches() == 0
