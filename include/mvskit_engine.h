@@ -131,6 +131,11 @@ int mvs_engine_download_patches(mvs_engine* e, int64_t cap, mvs_patch* out, int6
 /* Propagate::run(iter), propagate.cpp:28-64: two colour passes, each = index build + sweep + commit */
 int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out);
 
+/* Filter::run (pmmvps/filter.cpp:25-49): filterOutside, filterExact, filterNeighbor(1), filterSmallGroups with the
+ * depth-map / m_vimages rebuilds in between; removed4 = patches removed by each of the four.  filterSmallGroups
+ * groups by connected components of the symmetrised neighbour relation. */
+int mvs_engine_filter(mvs_engine* e, int64_t* removed4);
+
 /* The same split for view-sharded runs: every rank holds the whole pool, sweeps its own views
  * (view_begin/view_stride) and exchanges what it created before every rank commits the union. */
 int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out); /* index build + sweep */

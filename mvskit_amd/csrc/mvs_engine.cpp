@@ -64,6 +64,7 @@ struct mvs_engine {
     // index
     DevBuf<int32_t> cnt, start, cursor, ids, vcnt, vstart, vcursor, vids, scan_tmp;
     DevBuf<CellEntry> fat, vfat;
+    DevBuf<int32_t> uf_parent, uf_size;  // Filter::filterSmallGroups union-find
     DevBuf<int32_t> cnt_alive, vcnt_alive;
     DevBuf<unsigned long long> dpgrid, best;
     bool index_valid = false;
@@ -191,46 +192,82 @@ DParams current_params(mvs_engine* e) {
 
 bool want_vgrid(const mvs_engine* e) { return e->prm.depth >= 2 && e->prm.enable_check; }
 
-// Index build: CSR of every (view, cell) list sorted by (ncc desc, id asc), trim to MAX_NUM_OF_PATCHES, depth maps.
-int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
+// One cell index (m_pgrids or m_vpgrids): count -> scan -> fill -> per-cell sort (ncc desc, id asc) [-> trim to
+// MAX_NUM_OF_PATCHES] -> compaction to alive entries, written out as fat CellEntry streams.
+int build_list(mvs_engine* e, bool vgrid, bool trim) {
     hipStream_t st = e->stream;
     const int64_t nc = e->total_cells;
     DParams p = current_params(e);
-    HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
+    DevBuf<int32_t>& cnt = vgrid ? e->vcnt : e->cnt;
+    DevBuf<int32_t>& start = vgrid ? e->vstart : e->start;
+    DevBuf<int32_t>& cursor = vgrid ? e->vcursor : e->cursor;
+    DevBuf<int32_t>& ids = vgrid ? e->vids : e->ids;
+    DevBuf<CellEntry>& fat = vgrid ? e->vfat : e->fat;
+    DevBuf<int32_t>& cnt_alive = vgrid ? e->vcnt_alive : e->cnt_alive;
+    HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
+    mvsk_index_count(p, vgrid ? nullptr : cnt.p, vgrid ? cnt.p : nullptr, st);
+    mvsk_exclusive_scan(cnt.p, start.p, nc, e->scan_tmp.p, st);
+    int32_t tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, start.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (int r = ids.ensure(tot + 16)) return r;
+    if (int r = fat.ensure(tot + 16)) return r;
+    p = current_params(e);
+    HIPCHK(hipMemsetAsync(cursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
+    mvsk_index_fill(p, vgrid ? nullptr : start.p, vgrid ? nullptr : cursor.p, vgrid ? nullptr : ids.p, vgrid ? start.p : nullptr,
+                    vgrid ? cursor.p : nullptr, vgrid ? ids.p : nullptr, st);
+    mvsk_index_sort_trim(p, start.p, ids.p, trim ? 1 : 0, e->misc.p + 3, st);
+    mvsk_index_finalize(p, start.p, ids.p, fat.p, cnt_alive.p, st);
+    return MVS_OK;
+}
+int build_depth(mvs_engine* e) {  // m_dpgrids from the alive pool
+    const DParams p = current_params(e);
+    HIPCHK(hipMemsetAsync(e->dpgrid.p, 0xff, (size_t)e->total_cells * sizeof(unsigned long long), e->stream));
+    mvsk_depth_maps(p, e->dpgrid.p, e->stream);
+    return MVS_OK;
+}
+// Index build of a propagation pass: seed scores, m_pgrids lists with the MAX_NUM_OF_PATCHES trim, m_vpgrids lists
+// (needed by Optim::check), depth maps.
+int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
+    hipStream_t st = e->stream;
+    const DParams p = current_params(e);
+    HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 3 * sizeof(unsigned long long), st));
     // PatchManager::sortPatches re-scores every patch whose m_ncc < 0 each time it meets it
     // (patch_manager.cpp:411-415); a wave that finds m_ncc >= 0 exits at once.
     mvsk_fill_ncc(p, e->misc.p + 1, st);
     e->ncc_dirty = false;
-    const bool vg = want_vgrid(e);
-    HIPCHK(hipMemsetAsync(e->cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
-    if (vg) HIPCHK(hipMemsetAsync(e->vcnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
-    mvsk_index_count(p, e->cnt.p, vg ? e->vcnt.p : nullptr, st);
-    mvsk_exclusive_scan(e->cnt.p, e->start.p, nc, e->scan_tmp.p, st);
-    if (vg) mvsk_exclusive_scan(e->vcnt.p, e->vstart.p, nc, e->scan_tmp.p, st);
-    int32_t tot = 0, vtot = 0;
-    HIPCHK(hipMemcpyAsync(&tot, e->start.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (vg) HIPCHK(hipMemcpyAsync(&vtot, e->vstart.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (int r = e->ids.ensure(tot + 16)) return r;
-    if (int r = e->fat.ensure(tot + 16)) return r;
-    if (vg) { if (int r = e->vids.ensure(vtot + 16)) return r; if (int r = e->vfat.ensure(vtot + 16)) return r; }
-    p = current_params(e);
-    HIPCHK(hipMemsetAsync(e->cursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
-    if (vg) HIPCHK(hipMemsetAsync(e->vcursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
-    mvsk_index_fill(p, e->start.p, e->cursor.p, e->ids.p, vg ? e->vstart.p : nullptr, vg ? e->vcursor.p : nullptr, vg ? e->vids.p : nullptr, st);
-    HIPCHK(hipMemsetAsync(e->misc.p + 3, 0, sizeof(unsigned long long), st));
-    mvsk_index_sort_trim(p, e->start.p, e->ids.p, 1, e->misc.p + 3, st);
-    if (vg) mvsk_index_sort_trim(p, e->vstart.p, e->vids.p, 0, e->misc.p + 3, st);
-    mvsk_index_finalize(p, e->start.p, e->ids.p, e->fat.p, e->cnt_alive.p, st);
-    if (vg) mvsk_index_finalize(p, e->vstart.p, e->vids.p, e->vfat.p, e->vcnt_alive.p, st);
-    HIPCHK(hipMemsetAsync(e->dpgrid.p, 0xff, (size_t)nc * sizeof(unsigned long long), st));
-    mvsk_depth_maps(p, e->dpgrid.p, st);
+    if (int r = build_list(e, false, true)) return r;
+    if (want_vgrid(e)) if (int r = build_list(e, true, false)) return r;
+    if (int r = build_depth(e)) return r;
     if (trimmed_out) {
         HIPCHK(hipMemcpyAsync(trimmed_out, e->misc.p + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     HIPCHK(hipGetLastError());
     e->index_valid = true;
+    return MVS_OK;
+}
+// Filter::setDepthMapsVGridsVPGridsAddPatchV, filter.cpp:628-655
+int filter_rebuild(mvs_engine* e, int additive) {
+    if (int r = build_list(e, false, false)) return r;
+    if (int r = build_depth(e)) return r;
+    mvsk_filter_vimages(current_params(e), additive, e->stream);
+    if (int r = build_list(e, true, false)) return r;
+    HIPCHK(hipGetLastError());
+    return MVS_OK;
+}
+// counts and applies the kill flags a filter stage has set
+int apply_kills(mvs_engine* e, int64_t* removed) {
+    hipStream_t st = e->stream;
+    *removed = 0;
+    if (e->pool_n == 0) return MVS_OK;
+    mvsk_kill_count(e->kill.p, e->pool_n, e->kill_cnt.p, st);
+    mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, e->scan_tmp.p, st);
+    int32_t nk = 0;
+    HIPCHK(hipMemcpyAsync(&nk, e->kill_base.p + e->pool_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    mvsk_apply_kill_flags(e->pool.p, e->kill.p, e->pool_n, st);
+    HIPCHK(hipStreamSynchronize(st));
+    *removed = nk;
     return MVS_OK;
 }
 
@@ -338,6 +375,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     free_views(e);
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
+    e->uf_parent.release(); e->uf_size.release();
     e->vcursor.release(); e->vids.release(); e->fat.release(); e->vfat.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
@@ -662,6 +700,51 @@ int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out) {  // Propa
     }
     e->timing = tt;
     if (out) *out = total;
+    return MVS_OK;
+}
+
+int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filter.cpp:25-49
+    if (!e || !e->have_views) { g_err = "mvs_engine_filter: views not set"; return MVS_ERR_STATE; }
+    if (e->staged) { g_err = "mvs_engine_filter: a pass is waiting for its commit"; return MVS_ERR_STATE; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->stream;
+    int64_t rem[4] = {0, 0, 0, 0};
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    HIPCHK(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
+    if (e->pool_n > 0) HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));
+    if (int r = filter_rebuild(e, 0)) return r;
+    mvsk_filter_outside(current_params(e), e->kill.p, st);                       // filterOutside
+    if (int r = apply_kills(e, &rem[0])) return r;
+    if (int r = filter_rebuild(e, 1)) return r;
+    HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
+    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, st);          // filterExact
+    if (int r = apply_kills(e, &rem[1])) return r;
+    if (int r = filter_rebuild(e, 1)) return r;
+    mvsk_filter_neighbor(current_params(e), e->kill.p, e->error_flag.p, st);     // filterNeighbor(1)
+    if (int r = apply_kills(e, &rem[2])) return r;
+    if (int r = filter_rebuild(e, 1)) return r;
+    {                                                                              // filterSmallGroups
+        int64_t alive = 0;
+        if (int r = mvs_engine_num_patches(e, &alive)) return r;
+        if (e->uf_parent.ensure(e->pool.cap) || e->uf_size.ensure(e->pool.cap)) return MVS_ERR_HIP;
+        const int threshold = (int)std::max<int64_t>(20, alive / 10000);
+        mvsk_groups(current_params(e), e->uf_parent.p, e->uf_size.p, threshold, e->kill.p, st);
+        if (int r = apply_kills(e, &rem[3])) return r;
+    }
+    if (int r = filter_rebuild(e, 1)) return r;
+    if (int r = compact_pool(e)) return r;
+    int32_t herr = 0;
+    HIPCHK(hipMemcpyAsync(&herr, e->error_flag.p, sizeof herr, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]);
+    e->timing = mvs_timing{};
+    e->timing.index_ms = ms;  // whole Filter::run
+    e->index_valid = false;
+    if (removed4) for (int k = 0; k < 4; ++k) removed4[k] = rem[k];
+    if (herr & 4) { g_err = "mvs_engine_filter: more than 512 neighbours of one patch (engine limit)"; return MVS_ERR_CAPACITY; }
     return MVS_OK;
 }
 

@@ -101,7 +101,7 @@ __global__ void k_index_count(DParams prm, int32_t* __restrict__ cnt, int32_t* _
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
     const F4 coord = ld4(p->coord);
-    const int n = min(p->nimages, MVS_LISTCAP);
+    const int n = cnt ? min(p->nimages, MVS_LISTCAP) : 0;
     for (int i = 0; i < n; ++i) {
         const DView* vw = prm.views + p->images[i];
         int ix, iy;
@@ -127,7 +127,7 @@ __global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
     const F4 coord = ld4(p->coord);
-    const int n = min(p->nimages, MVS_LISTCAP);
+    const int n = start ? min(p->nimages, MVS_LISTCAP) : 0;
     for (int i = 0; i < n; ++i) {
         const DView* vw = prm.views + p->images[i];
         int ix, iy;
@@ -482,6 +482,177 @@ __global__ void k_alive_gather(const DPatch* __restrict__ pool, int64_t n, const
     out[base[i]].id = (int32_t)i;
 }
 
+// =================================================================== Filter::run (pmmvps/filter.cpp:25-49)
+DEV void set_vgrids(const DParams& prm, const WaveCtx& wc, Cand& c) {  // PatchManager::setVGrids, patch_manager.cpp:252-261
+    c.vgx = 0; c.vgy = 0;
+    if (wc.lane < c.nvimg) cell_of(prm, prm.views + c.vimg, c.coord, c.vgx, c.vgy);
+}
+DEV void store_lists(DPatch* p, const WaveCtx& wc, const Cand& c) {
+    if (wc.lane == 0) { p->nimages = c.nimg; p->nvimages = c.nvimg; }
+    if (wc.lane < MVS_MAXI) {
+        p->images[wc.lane] = (uint8_t)(wc.lane < c.nimg ? c.img : 0);
+        p->vimages[wc.lane] = (uint8_t)(wc.lane < c.nvimg ? c.vimg : 0);
+    }
+}
+// Filter::setVGridsVPGrids (filter.cpp:657-664): m_vimages cleared (additive == 0) or kept, then setVImagesVGrids
+__global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive) {
+    __shared__ int s_scratch[192];
+    DPatch* p = prm.pool + blockIdx.x;
+    if (!(p->flags & 1)) return;
+    WaveCtx wc = make_wave_ctx(prm);
+    Cand c;
+    load_cand(p, wc, c);
+    if (!additive) c.nvimg = 0;
+    set_vgrids(prm, wc, c);
+    set_vimages_vgrids(prm, wc, s_scratch, c);
+    store_lists(p, wc, c);
+}
+// Filter::filterOutside, filter.cpp:51-106: gain < 0 -> removed
+__global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kill) {
+    __shared__ int s_dummy[1];
+    const DPatch* p = prm.pool + blockIdx.x;
+    if (!(p->flags & 1)) return;
+    WaveCtx wc = make_wave_ctx(prm);
+    Cand c;
+    load_cand(p, wc, c);
+    set_grids(prm, wc, c);
+    set_vgrids(prm, wc, c);
+    const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy};
+    const float gain = compute_gain(prm, wc, cx, c);
+    if (wc.lane == 0 && gain < 0.0f) kill[blockIdx.x] = 1;
+}
+// Filter::filterExact, filter.cpp:148-263
+__global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill, unsigned long long* evals) {
+    __shared__ int s_scratch[192];
+    extern __shared__ float s_texs[];
+    DPatch* p = prm.pool + blockIdx.x;
+    if (!(p->flags & 1)) return;
+    WaveCtx wc = make_wave_ctx(prm);
+    Cand c;
+    load_cand(p, wc, c);
+    set_grids(prm, wc, c);
+    // view lane i: does view m_images[i] survive?  (filterExactSub: own cell, then the 4 neighbouring cells)
+    bool safe = false;
+    if (wc.lane < c.nimg) {
+        const int image = c.img, x = c.gx, y = c.gy;
+        const DView* vw = prm.views + image;
+        const int w = vw->gw, h = vw->gh;
+        if (!(x < 0 || w <= x || y < 0 || h <= y)) {
+            const float thr = prm.neighborThreshold1;
+            safe = is_visible(prm, c, image, x, y, thr) || (0 < x && is_visible(prm, c, image, x - 1, y, thr)) ||
+                   (x < w - 1 && is_visible(prm, c, image, x + 1, y, thr)) || (0 < y && is_visible(prm, c, image, x, y - 1, thr)) ||
+                   (y < h - 1 && is_visible(prm, c, image, x, y + 1, thr));
+        }
+    }
+    // the survivors in ascending view order (the image-major loop of filterExactSub)
+    __syncthreads();
+    if (wc.lane < MVS_MAXVIEWS) s_scratch[wc.lane] = 0;
+    __syncthreads();
+    if (safe) s_scratch[c.img] = 1;
+    __syncthreads();
+    const bool present = s_scratch[wc.lane] != 0;
+    const unsigned long long pm = ballot(present);
+    const int pos = __popcll(pm & ((1ull << wc.lane) - 1ull));
+    __syncthreads();
+    if (present && pos < MVS_LISTCAP) s_scratch[64 + pos] = wc.lane;
+    __syncthreads();
+    c.nimg = min((int)__popcll(pm), MVS_LISTCAP);
+    c.img = s_scratch[64 + wc.lane];
+    if (prm.minImageNum <= c.nimg) {
+        const int tstride = (prm.wsz + 3) & ~3;
+        set_ref_image(prm, wc, s_texs, tstride, c);
+        store_lists(p, wc, c);
+    } else {
+        if (wc.lane == 0) kill[blockIdx.x] = 1;
+    }
+    if (wc.lane == 0) { atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
+}
+// Filter::filterNeighbor(1), filter.cpp:265-327: fewer than 6 neighbours, or a bad quadric fit
+__global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* kill, int32_t* overflow) {
+    extern __shared__ float s_lds[];
+    __shared__ int s_dummy[1];
+    const DPatch* p = prm.pool + blockIdx.x;
+    if (!(p->flags & 1)) return;
+    WaveCtx wc = make_wave_ctx(prm);
+    Cand c;
+    load_cand(p, wc, c);
+    set_grids(prm, wc, c);
+    const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy};
+    int* table = reinterpret_cast<int*>(s_lds);
+    int n = find_neighbors(prm, wc, cx, c, table, 4.0f, 2);
+    bool reject = n < 6;
+    if (!reject) {
+        if (n > MVS_ROW_CAP) { n = MVS_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }
+        reject = filter_quad(prm, wc, cx, c, table, n, s_lds + MVS_HASH_CAP) != 0;
+    }
+    if (wc.lane == 0 && reject) kill[blockIdx.x] = 1;
+}
+// Filter::filterSmallGroups, filter.cpp:432-578, as connected components of the symmetrised relation: lock-free
+// union-find, the smaller id becomes the root.
+DEV int uf_find(int* parent, int a) {
+    while (true) {
+        const int pa = __atomic_load_n(&parent[a], __ATOMIC_RELAXED);
+        if (pa == a) return a;
+        const int gp = __atomic_load_n(&parent[pa], __ATOMIC_RELAXED);
+        if (gp != pa) __atomic_store_n(&parent[a], gp, __ATOMIC_RELAXED);
+        a = pa;
+    }
+}
+DEV void uf_union(int* parent, int a, int b) {
+    while (true) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        if (atomicCAS(&parent[b], b, a) == b) return;
+    }
+}
+__global__ void k_groups_init(int* parent, int* size, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { parent[i] = (int)i; size[i] = 0; }
+}
+__global__ void k_groups_union(DParams prm, int* parent) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= prm.pool_n) return;
+    const DPatch* p = prm.pool + id;
+    if (!(p->flags & 1)) return;
+    const PGeo me = load_geo(p);
+    const DView* vw = prm.views + me.ref;
+    int gx, gy;
+    cell_of(prm, vw, me.coord, gx, gy);
+    for (int y = -1; y <= 1; ++y) {
+        const int yt = gy + y;
+        if (yt < 0 || vw->gh <= yt) continue;
+        for (int x = -1; x <= 1; ++x) {
+            const int xt = gx + x;
+            if (xt < 0 || vw->gw <= xt) continue;
+            const int g = vw->cell_base + yt * vw->gw + xt;
+            for (int kind = 0; kind < 2; ++kind) {
+                const CellEntry* fe = kind == 0 ? prm.csr_fat + prm.csr_start[g] : prm.vcsr_fat + prm.vcsr_start[g];
+                const int n = kind == 0 ? prm.csr_cnt[g] : prm.vcsr_cnt[g];
+                for (int j = 0; j < n; ++j) {
+                    const CellEntry e = fe[j];
+                    if (e.id == (int)id) continue;
+                    const PGeo q{{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
+                    if (is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) uf_union(parent, (int)id, e.id);
+                }
+            }
+        }
+    }
+}
+__global__ void k_groups_count(DParams prm, int* parent, int* size) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= prm.pool_n || !(prm.pool[id].flags & 1)) return;
+    const int r = uf_find(parent, (int)id);
+    parent[id] = r;
+    atomicAdd(&size[r], 1);
+}
+__global__ void k_groups_kill(DParams prm, const int* parent, const int* size, int threshold, uint8_t* kill) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= prm.pool_n || !(prm.pool[id].flags & 1)) return;
+    if (size[parent[id]] < threshold) kill[id] = 1;
+}
+
 // =================================================================== probes (single functions, batched)
 __global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, const DPatch* __restrict__ in, const float* __restrict__ in_f,
                                               DPatch* __restrict__ out, float* __restrict__ out_f, int32_t* __restrict__ out_i) {
@@ -530,6 +701,17 @@ __global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, co
         cost_func3(prm, wc, rc, __shfl(c.img, wc.lane & 15), c.nimg, false, x[0], x[1], x[2], f, fu1, fu2);
         if (wc.lane == 0) out_f[i] = (float)f;
     }
+}
+
+// refinePatch alone (occupancy experiment / kernel benchmark): same arithmetic as probe op 2
+__global__ __launch_bounds__(64) void k_probe_refine(DParams prm, int64_t n, const DPatch* __restrict__ in, DPatch* __restrict__ out) {
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    WaveCtx wc = make_wave_ctx(prm);
+    Cand c;
+    load_cand(in + i, wc, c);
+    refine_patch(prm, wc, c, 0u, 0u, (uint32_t)i, 0u);
+    store_cand(out + i, wc, c, 1, (int)i);
 }
 
 // =================================================================== host-callable launchers
@@ -599,6 +781,26 @@ void mvsk_alive_count(const DPatch* pool, int64_t n, int32_t* cnt, hipStream_t s
 void mvsk_alive_gather(const DPatch* pool, int64_t n, const int32_t* base, DPatch* out, int64_t cap, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_alive_gather, dim3(nblk(n, 256)), dim3(256), 0, st, pool, n, base, out, cap);
 }
+void mvsk_filter_vimages(const DParams& prm, int additive, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_vimages, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, additive);
+}
+void mvsk_filter_outside(const DParams& prm, uint8_t* kill, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_outside, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, kill);
+}
+void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)prm.pool_n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals);
+}
+void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* overflow, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_neighbor, dim3((unsigned)prm.pool_n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, overflow);
+}
+void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st) {
+    if (prm.pool_n <= 0) return;
+    hipLaunchKernelGGL(k_groups_init, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, parent, size, prm.pool_n);
+    hipLaunchKernelGGL(k_groups_union, dim3(nblk(prm.pool_n, 128)), dim3(128), 0, st, prm, parent);
+    hipLaunchKernelGGL(k_groups_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size);
+    hipLaunchKernelGGL(k_groups_kill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size, threshold, kill);
+}
 void mvsk_probe(const DParams& prm, int op, int64_t n, const DPatch* in, const float* in_f, DPatch* out, float* out_f, int32_t* out_i, hipStream_t st) {
+    if (n > 0 && op == 2) { hipLaunchKernelGGL(k_probe_refine, dim3((unsigned)n), dim3(64), 0, st, prm, n, in, out); return; }
     if (n > 0) hipLaunchKernelGGL(k_probe, dim3((unsigned)n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, op, n, in, in_f, out, out_f, out_i);
 }

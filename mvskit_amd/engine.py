@@ -21,6 +21,7 @@ EXPORTS = [
     "mvs_engine_clear_patches", "mvs_engine_num_patches", "mvs_engine_download_patches", "mvs_engine_propagate",
     "mvs_engine_pass", "mvs_engine_export_counts", "mvs_engine_export_device", "mvs_engine_commit_device",
     "mvs_engine_commit_local", "mvs_engine_depth_normal_map", "mvs_engine_probe", "mvs_engine_last_timing",
+    "mvs_engine_filter",
 ]
 
 
@@ -96,6 +97,7 @@ def load_library():
     L.mvs_engine_depth_normal_map.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.mvs_engine_probe.argtypes = [vp, C.c_int, C.c_int64, vp, vp, vp, vp, vp]
     L.mvs_engine_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.mvs_engine_filter.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -206,6 +208,11 @@ class Engine:
         c = Counters()
         self._check(self.L.mvs_engine_propagate(self.h, it, C.byref(c)))
         return c.as_dict()
+
+    def filter(self):
+        r = np.zeros(4, dtype=np.int64)
+        self._check(self.L.mvs_engine_filter(self.h, _ptr(r)))
+        return {"outside": int(r[0]), "exact": int(r[1]), "neighbor": int(r[2]), "groups": int(r[3])}
 
     def engine_pass(self, it, p):
         c = Counters()

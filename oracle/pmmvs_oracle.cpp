@@ -1132,6 +1132,166 @@ int check_patch(const Scene& s, Patch& p, const DestCtx* ctx) {
     return 0;
 }
 
+/* ------------------------------------------------------------------ Filter::run (pmmvps/filter.cpp:25-49) */
+void set_ref_image(const Scene& s, Patch& p, orc_counters* cnt);
+void build_csr(Scene& s, bool vgrid);
+void build_depth_maps(Scene& s);
+void rebuild_live_from_pool(Scene& s);
+
+/* Filter::setDepthMapsVGridsVPGridsAddPatchV, filter.cpp:628-655: depth maps from the alive patches, m_vimages
+ * recomputed (additive == 0) or extended (additive == 1), both cell indices rebuilt.  No MAX_NUM_OF_PATCHES trim here. */
+void filter_rebuild(Scene& s, int additive) {
+    for (Patch& p : s.pool) if (p.alive) set_grids(s, p);
+    build_csr(s, false);
+    build_depth_maps(s);
+    for (Patch& p : s.pool) {
+        if (!p.alive) continue;
+        if (additive == 0) p.nvimg = 0;
+        set_vgrids(s, p);
+        set_vimages_vgrids(s, p, nullptr);
+    }
+    build_csr(s, true);
+    if (s.cfg.schedule == ORC_SCHEDULE_FAITHFUL) rebuild_live_from_pool(s);
+}
+
+/* Filter::filterOutside, filter.cpp:51-106: all gains on the same snapshot, then the removals */
+int filter_outside(Scene& s) {
+    std::vector<int> dead;
+    for (size_t id = 0; id < s.pool.size(); ++id)
+        if (s.pool[id].alive && compute_gain(s, s.pool[id], nullptr) < 0.0f) dead.push_back((int)id);
+    for (int id : dead) s.pool[id].alive = false;
+    return (int)dead.size();
+}
+
+/* Filter::filterExact, filter.cpp:148-263: a view stays in m_images if the patch passes the depth-map test in its
+ * cell or one of the 4 neighbouring cells (filterExactSub 211-263); the surviving views are listed in ascending
+ * view order (the image-major loop), the reference view is re-picked (setRefImage), too few views = removal. */
+int filter_exact(Scene& s) {
+    int removed = 0;
+    std::vector<Patch> updated;
+    std::vector<int> ids;
+    for (size_t id = 0; id < s.pool.size(); ++id) {
+        Patch p = s.pool[id];
+        if (!p.alive) continue;
+        int keepv[256], nk = 0;
+        for (int image = 0; image < s.cfg.nviews; ++image) {
+            int k = -1;
+            for (int i = 0; i < p.nimg; ++i) if (p.img[i] == image) { k = i; break; }
+            if (k < 0) continue;
+            const View& vw = s.views[image];
+            const int x = p.gx[k], y = p.gy[k], w = vw.gw, h = vw.gh;
+            if (x < 0 || w <= x || y < 0 || h <= y) continue; /* not in any m_pgrids list */
+            int safe = 0;
+            if (is_visible(s, p, image, x, y, s.neighborThreshold1, nullptr)) safe = 1;
+            else if (0 < x && is_visible(s, p, image, x - 1, y, s.neighborThreshold1, nullptr)) safe = 1;
+            else if (x < w - 1 && is_visible(s, p, image, x + 1, y, s.neighborThreshold1, nullptr)) safe = 1;
+            else if (0 < y && is_visible(s, p, image, x, y - 1, s.neighborThreshold1, nullptr)) safe = 1;
+            else if (y < h - 1 && is_visible(s, p, image, x, y + 1, s.neighborThreshold1, nullptr)) safe = 1;
+            if (safe) keepv[nk++] = image;
+        }
+        p.nimg = std::min(nk, LISTCAP);
+        for (int i = 0; i < p.nimg; ++i) p.img[i] = keepv[i];
+        if (s.cfg.minImageNum <= p.nimg) { set_ref_image(s, p, &s.cnt); set_grids(s, p); }
+        else { p.alive = false; ++removed; }
+        updated.push_back(p);
+        ids.push_back((int)id);
+    }
+    for (size_t k = 0; k < ids.size(); ++k) s.pool[ids[k]] = updated[k];
+    return removed;
+}
+
+/* Filter::filterNeighbor(1), filter.cpp:265-327 */
+int filter_neighbor(Scene& s) {
+    std::vector<int> dead;
+    for (size_t id = 0; id < s.pool.size(); ++id) {
+        if (!s.pool[id].alive) continue;
+        std::vector<int> nb;
+        find_neighbors(s, s.pool[id], nb, 4.0f, 2, nullptr);
+        if ((int)nb.size() < 6 || filter_quad(s, s.pool[id], nb, nullptr)) dead.push_back((int)id);
+    }
+    for (int id : dead) s.pool[id].alive = false;
+    return (int)dead.size();
+}
+
+/* Filter::filterSmallGroups, filter.cpp:432-578.  Patch q hangs on patch p when q is listed (m_pgrids or m_vpgrids) in
+ * one of the 3x3 cells around p in p's reference view and isNeighbor(p, q, m_neighborThreshold2).
+ * FAITHFUL: the reference's breadth-first labelling in patch order (the relation is directed, so the grouping depends
+ * on that order).  ENGINE: connected components of the symmetrised relation (union-find).  Groups smaller than
+ * max(20, N / 10000) are removed. */
+void small_group_edges(const Scene& s, int pid, std::vector<int>& out) {
+    const Patch& p = s.pool[pid];
+    const int v = p.img[0];
+    const View& vw = s.views[v];
+    for (int y = -1; y <= 1; ++y) {
+        const int yt = p.gy[0] + y;
+        if (yt < 0 || vw.gh <= yt) continue;
+        for (int x = -1; x <= 1; ++x) {
+            const int xt = p.gx[0] + x;
+            if (xt < 0 || vw.gw <= xt) continue;
+            for (int kind = 0; kind < 2; ++kind) {
+                const Span l = cell_list(s, kind, v, yt * vw.gw + xt, nullptr);
+                for (int j = 0; j < l.n; ++j)
+                    if (is_neighbor(s, p, s.pool[l.p[j]], s.neighborThreshold2)) out.push_back(l.p[j]);
+            }
+        }
+    }
+}
+int filter_small_groups(Scene& s) {
+    std::vector<int> alive;
+    for (size_t id = 0; id < s.pool.size(); ++id) if (s.pool[id].alive) alive.push_back((int)id);
+    const int psize = (int)alive.size();
+    if (psize == 0) return 0;
+    std::vector<int> label(s.pool.size(), -1);
+    int ngroups = 0;
+    if (s.cfg.schedule == ORC_SCHEDULE_FAITHFUL) {
+        for (int root : alive) {
+            if (label[root] != -1) continue;
+            const int id = ngroups++;
+            label[root] = id;
+            std::vector<int> queue{root};
+            for (size_t qh = 0; qh < queue.size(); ++qh) {
+                std::vector<int> e;
+                small_group_edges(s, queue[qh], e);
+                for (int q : e) if (label[q] == -1) { label[q] = id; queue.push_back(q); }
+            }
+        }
+    } else {
+        std::vector<int> parent(s.pool.size());
+        for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
+        auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+        for (int pid : alive) {
+            std::vector<int> e;
+            small_group_edges(s, pid, e);
+            for (int q : e) {
+                int a = find(pid), b = find(q);
+                if (a == b) continue;
+                if (a > b) std::swap(a, b);
+                parent[b] = a; /* smaller id is the root */
+            }
+        }
+        for (int pid : alive) label[pid] = find(pid);
+        ngroups = (int)s.pool.size();
+    }
+    std::vector<int> size(std::max(ngroups, 1), 0);
+    for (int pid : alive) ++size[label[pid]];
+    const int threshold = std::max(20, psize / 10000);
+    int removed = 0;
+    for (int pid : alive) if (size[label[pid]] < threshold) { s.pool[pid].alive = false; ++removed; }
+    return removed;
+}
+
+void filter_run(Scene& s, int64_t* removed4) {
+    filter_rebuild(s, 0);
+    removed4[0] = filter_outside(s);
+    filter_rebuild(s, 1);
+    removed4[1] = filter_exact(s);
+    filter_rebuild(s, 1);
+    removed4[2] = filter_neighbor(s);
+    filter_rebuild(s, 1);
+    removed4[3] = filter_small_groups(s);
+    filter_rebuild(s, 1);
+}
+
 /* PhotoSet::getMask(coord, level), photoSet.cpp:223-233 + Photo::getMask, photo.cpp:48-55 */
 int get_mask_all(const Scene& s, const V4& coord) {
     for (int v = 0; v < s.cfg.nviews; ++v) {
@@ -1761,6 +1921,13 @@ int orc_propagate(orc_scene* h, int iter, orc_counters* out) { /* Propagate::run
         for (Patch& p : s.pool) if (p.alive) { set_grids(s, p); set_vgrids(s, p); }
     }
     if (out) *out = total;
+    return 0;
+}
+
+int orc_filter(orc_scene* h, int64_t* removed4) { /* Filter::run, filter.cpp:25-49 */
+    int64_t r[4] = {0, 0, 0, 0};
+    filter_run(h->s, r);
+    if (removed4) for (int k = 0; k < 4; ++k) removed4[k] = r[k];
     return 0;
 }
 

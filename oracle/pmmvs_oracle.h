@@ -105,6 +105,8 @@ int orc_get_patches(orc_scene* s, int cap, orc_patch* out);    /* alive patches 
 int orc_clear_patches(orc_scene* s);
 
 int orc_propagate(orc_scene* s, int iter, orc_counters* out);  /* Propagate::run(iter) */
+/* Filter::run (filter.cpp:25-49): removed4 = patches removed by filterOutside / Exact / Neighbor / SmallGroups */
+int orc_filter(orc_scene* s, int64_t* removed4);
 /* faithful schedule only: bound the work (for timing a sample). <=0 means unlimited. */
 int orc_set_cell_budget(orc_scene* s, int64_t max_source_cells);
 int orc_set_time_budget(orc_scene* s, double seconds);

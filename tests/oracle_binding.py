@@ -76,6 +76,7 @@ def lib():
     L.orc_get_patches.argtypes = [vp, C.c_int, vp]
     L.orc_clear_patches.argtypes = [vp]
     L.orc_propagate.argtypes = [vp, C.c_int, C.POINTER(Counters)]
+    L.orc_filter.argtypes = [vp, vp]
     L.orc_set_cell_budget.argtypes = [vp, C.c_int64]
     L.orc_set_time_budget.argtypes = [vp, C.c_double]
     L.orc_engine_pass.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Counters)]
@@ -223,6 +224,11 @@ class Oracle:
         if self.L.orc_propagate(self.h, it, C.byref(c)) != 0:
             raise RuntimeError(self.L.orc_last_error().decode())
         return c.as_dict()
+
+    def filter(self):
+        r = np.zeros(4, dtype=np.int64)
+        self.L.orc_filter(self.h, _ptr(r))
+        return {"outside": int(r[0]), "exact": int(r[1]), "neighbor": int(r[2]), "groups": int(r[3])}
 
     def set_cell_budget(self, n):
         self.L.orc_set_cell_budget(self.h, n)

@@ -312,3 +312,26 @@ def test_empty_pool_and_reupload(small_plane_scene):
     assert e.num_patches() == int((ragged["nimages"] > 0).sum())
     e.clear_patches()
     assert e.num_patches() == 0
+
+
+def test_filter_run_matches_oracle(small_multi_scene):
+    """Filter::run (filter.cpp:25-49) after each Propagate::run, as PmMvps::run does (pmmvps.cpp:95-105)."""
+    sc = small_multi_scene
+    o, e = _pair(sc, seed=21, enable_check=1)
+    seeds = synth.make_seeds(sc, stride=3, seed=19)
+    o.add_patches(seeds)
+    e.upload_patches(seeds)
+    for it in range(2):
+        co, ce = o.propagate(it), e.propagate(it)
+        assert co == ce, (it, co, ce)
+        fo, fe = o.filter(), e.filter()
+        assert fo == fe, (it, fo, fe)
+        assert fo["outside"] + fo["exact"] > 0
+        po, pe = o.patches(), e.patches()
+        assert po.shape == pe.shape
+        np.testing.assert_array_equal(po["images"], pe["images"])      # filterExact rewrites m_images and the reference view
+        np.testing.assert_array_equal(po["nvimages"], pe["nvimages"])  # setDepthMapsVGridsVPGridsAddPatchV rebuilds m_vimages
+        np.testing.assert_array_equal(po["vimages"], pe["vimages"])
+        np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+        o.update_threshold()
+        e.update_threshold()
