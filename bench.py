@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--seed-stride", type=int, default=2, help="one seed patch per stride x stride cells per view")
     ap.add_argument("--refine-steps", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--filter", action="store_true", help="BASELINE config 5: run Filter::run (filter.cpp:25-49) after every iteration, inside the timed region")
     ap.add_argument("--scene-cache", default=os.path.join("/tmp", "mvskit_scene_cache"))
     return ap.parse_args()
 
@@ -134,10 +135,14 @@ def main():
         ts = time.perf_counter()
         c = ex.propagate(e, it) if ex else e.propagate(it)
         t = e.timing()
+        if args.filter:
+            tf = time.perf_counter()
+            c["filter_removed"] = e.filter()
+            t["filter_ms"] = 1000.0 * (time.perf_counter() - tf)
         e.update_threshold()
         if rank == 0:
             log(f"iter {it}: {time.perf_counter() - ts:.3f} s, patches {c['patches']}, candidates {c['candidates']}, view_evals {c['view_evals']}, "
-                f"inserted {c['inserted']}, replaced {c['replaced']}, timing {t}")
+                f"inserted {c['inserted']}, replaced {c['replaced']}, timing {t}" + (f", filter removed {c['filter_removed']}" if args.filter else ""))
         return c, t
 
     it = 0
@@ -187,7 +192,7 @@ def main():
             "config": {"workload": f"{args.views}-view {args.width}x{args.height} synthetic scene (3 planes + sphere), level 0, csize 2, wsize 7, "
                                    f"minImageNum 3, 1 seed per {args.seed_stride}x{args.seed_stride} cells per view, {args.steps} iterations after {args.warmup} warm-up",
                        "views": args.views, "width": args.width, "height": args.height, "csize": 2, "wsize": 7,
-                       "refine_evals": 1 + 3 * args.refine_steps, "check_depth2": True,
+                       "refine_evals": 1 + 3 * args.refine_steps, "check_depth2": True, "filter_run": bool(args.filter),
                        "parallelism": "single GPU" if world == 1 else f"views sharded over {world} GPUs, RCCL all-gather of patch records per colour pass"},
             "patches": patches,
             "view_evals": view_evals,

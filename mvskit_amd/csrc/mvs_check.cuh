@@ -11,9 +11,15 @@
 
 namespace mvsdev {
 
-#define MVS_HASH_CAP 1024  // ints: hash set / sorted id list of the neighbours
-#define MVS_ROW_CAP 512    // neighbours kept for filterQuad (3 floats each)
+// LDS of the neighbour search: a hash set / sorted id list of HCAP ints and 3 floats per neighbour kept for filterQuad.
+// Optim::check (inside the sweep) uses the small configuration; Filter::filterNeighbor, which sees the untrimmed lists
+// of every patch, the large one.
+#define MVS_HASH_CAP 1024
+#define MVS_ROW_CAP 512
 #define MVS_CHECK_LDS_FLOATS (MVS_HASH_CAP + 3 * MVS_ROW_CAP)
+#define MVS_FILTER_HASH_CAP 4096
+#define MVS_FILTER_ROW_CAP 2048
+#define MVS_FILTER_LDS_FLOATS (MVS_FILTER_HASH_CAP + 3 * MVS_FILTER_ROW_CAP)
 
 struct CheckCtx {
     const DPatch* staging;  // records created by this pass (ids >= MVS_NEWBASE)
@@ -111,6 +117,7 @@ DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
 
 // PatchManager::findNeighbors, patch_manager.cpp:671-728 (scale 4, margin 2 as Optim::check calls it).
 // Leaves the sorted unique ids in `table[0..count)` (LDS, MVS_HASH_CAP ints) and returns count.
+template <int HCAP>
 DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin) {
     const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
     // Propagate::computeRadius, propagate.cpp:474-481: the second smallest unit
@@ -138,7 +145,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     }
     const float thr = prm.neighborThreshold * scale;
     __syncthreads();
-    for (int t = wc.lane; t < MVS_HASH_CAP; t += 64) table[t] = -1;
+    for (int t = wc.lane; t < HCAP; t += 64) table[t] = -1;
     __syncthreads();
     const int side = 2 * margin + 1, per = side * side;
     const int ntask = c.nimg * per;
@@ -157,13 +164,13 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
                         // a patch shows up in the cells of several views: the set remembers every id it has seen
                         // (id = tested and accepted, -2 - id = tested and rejected), the predicate runs once per id
                         const int id = l.live ? cx.live_ids[j] : l.fat[j].id;
-                        unsigned h = (mix32((uint32_t)id)) & (MVS_HASH_CAP - 1);
+                        unsigned h = (mix32((uint32_t)id)) & (HCAP - 1);
                         bool fresh = false;
-                        for (int probe = 0; probe < MVS_HASH_CAP; ++probe) {
+                        for (int probe = 0; probe < HCAP; ++probe) {
                             const int old = atomicCAS(&table[h], -1, id);
                             if (old == -1) { fresh = true; break; }
                             if (old == id || old == -2 - id) break;
-                            h = (h + 1) & (MVS_HASH_CAP - 1);
+                            h = (h + 1) & (HCAP - 1);
                         }
                         if (!fresh) continue;
                         int id2;
@@ -177,12 +184,12 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     __syncthreads();
     // compact the set to the front of the table
     int count = 0;
-    int mine[MVS_HASH_CAP / 64];
+    int mine[HCAP / 64];
 #pragma unroll
-    for (int k = 0; k < MVS_HASH_CAP / 64; ++k) mine[k] = table[k * 64 + wc.lane];
+    for (int k = 0; k < HCAP / 64; ++k) mine[k] = table[k * 64 + wc.lane];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < MVS_HASH_CAP / 64; ++k) {
+    for (int k = 0; k < HCAP / 64; ++k) {
         const bool has = mine[k] >= 0;
         const unsigned long long m = ballot(has);
         if (has) table[count + __popcll(m & ((1ull << wc.lane) - 1ull))] = mine[k];
@@ -346,7 +353,7 @@ DEV int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, C
     if (gain < 0.0f) { c.nimg = 0; return 1; }
     if (MVS_CHECK_STAGES < 2) return 0;
     int* table = reinterpret_cast<int*>(lds);
-    int n = find_neighbors(prm, wc, cx, c, table, 4.0f, 2);
+    int n = find_neighbors<MVS_HASH_CAP>(prm, wc, cx, c, table, 4.0f, 2);
     if (MVS_CHECK_STAGES < 3) return 0;
     if (6 < n) {
         if (n > MVS_ROW_CAP) { n = MVS_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }

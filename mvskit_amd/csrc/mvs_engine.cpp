@@ -744,7 +744,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     e->timing.index_ms = ms;  // whole Filter::run
     e->index_valid = false;
     if (removed4) for (int k = 0; k < 4; ++k) removed4[k] = rem[k];
-    if (herr & 4) { g_err = "mvs_engine_filter: more than 512 neighbours of one patch (engine limit)"; return MVS_ERR_CAPACITY; }
+    if (herr & 4) { g_err = "mvs_engine_filter: more than 2048 neighbours of one patch (engine limit)"; return MVS_ERR_CAPACITY; }
     return MVS_OK;
 }
 

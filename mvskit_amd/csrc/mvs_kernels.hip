@@ -579,11 +579,11 @@ __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* ki
     set_grids(prm, wc, c);
     const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy};
     int* table = reinterpret_cast<int*>(s_lds);
-    int n = find_neighbors(prm, wc, cx, c, table, 4.0f, 2);
+    int n = find_neighbors<MVS_FILTER_HASH_CAP>(prm, wc, cx, c, table, 4.0f, 2);
     bool reject = n < 6;
     if (!reject) {
-        if (n > MVS_ROW_CAP) { n = MVS_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }
-        reject = filter_quad(prm, wc, cx, c, table, n, s_lds + MVS_HASH_CAP) != 0;
+        if (n > MVS_FILTER_ROW_CAP) { n = MVS_FILTER_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }
+        reject = filter_quad(prm, wc, cx, c, table, n, s_lds + MVS_FILTER_HASH_CAP) != 0;
     }
     if (wc.lane == 0 && reject) kill[blockIdx.x] = 1;
 }
@@ -791,7 +791,7 @@ void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* ev
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)prm.pool_n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals);
 }
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* overflow, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_neighbor, dim3((unsigned)prm.pool_n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, overflow);
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_neighbor, dim3((unsigned)prm.pool_n), dim3(64), (size_t)MVS_FILTER_LDS_FLOATS * sizeof(float), st, prm, kill, overflow);
 }
 void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st) {
     if (prm.pool_n <= 0) return;

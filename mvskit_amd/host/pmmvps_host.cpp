@@ -304,8 +304,19 @@ int Propagate::run(const int iter) {  // propagate.cpp:28-64: the drop-in bounda
     return 0;
 }
 
+// ------------------------------------------------------------------ Filter
+int Filter::run() {  // filter.cpp:25-49
+    int64_t r4[4] = {0, 0, 0, 0};
+    int r = mvs_engine_set_thresholds(m_pmmvps.m_engine, m_pmmvps.m_nccThreshold, m_pmmvps.m_nccThresholdBefore, m_pmmvps.m_depth);
+    if (r == 0) r = mvs_engine_filter(m_pmmvps.m_engine, r4);
+    if (r != 0) { cerr << "Filter::run: " << mvs_last_error() << endl; return r; }
+    for (int k = 0; k < 4; ++k) m_removed[k] = r4[k];
+    cerr << "FilterOutside/Exact/Neighbor/Groups removed: " << r4[0] << " " << r4[1] << " " << r4[2] << " " << r4[3] << endl;
+    return 0;
+}
+
 // ------------------------------------------------------------------ PmMvps
-PmMvps::PmMvps() : m_patchManager(*this), m_propagate(*this) {}
+PmMvps::PmMvps() : m_patchManager(*this), m_propagate(*this), m_filter(*this) {}
 PmMvps::~PmMvps() { if (m_engine) mvs_engine_destroy(m_engine); }
 
 int PmMvps::createEngine(float maxAngle, float quad) {
@@ -349,6 +360,7 @@ int PmMvps::init(const Option& option, const PhotoSet& photos) {  // pmmvps.cpp:
     if (int r = createEngine(option.m_maxAngleThreshold, option.m_quadThreshold)) return r;
     m_patchManager.init();
     m_propagate.init();
+    m_filter.init();
     return 0;
 }
 int PmMvps::init(const Option& option) {
@@ -365,7 +377,7 @@ int PmMvps::run() {  // pmmvps.cpp:76-114
         cerr << "\n---------------------\nIteration: " << iter << "\n---------------------" << endl;
         if (int r = m_propagate.run(iter)) return r;
         if (m_writeFiles) m_patchManager.writePatches(m_prefix + "ply/refined_patches_before_refine_" + std::to_string(iter), true, false, false);
-        // Filter::run (pmmvps.cpp:101) is outside the engine's current scope
+        if (int r = m_filter.run()) return r;  // pmmvps.cpp:101
         updateThreshold();
         ++m_depth;
         if (m_writeFiles) m_patchManager.writePatches(m_prefix + "ply/refined_patches_" + std::to_string(iter), true, false, false);
@@ -399,6 +411,7 @@ extern "C" int mvshost_run(int nviews, int width, int height, const float* P /*[
     for (int iter = 0; iter < iters; ++iter) {
         if (int r = pmmvps.m_propagate.run(iter)) return r;
         total += pmmvps.m_propagate.m_ecount;
+        if (int r = pmmvps.m_filter.run()) return r;
         pmmvps.updateThreshold();
         ++pmmvps.m_depth;
     }

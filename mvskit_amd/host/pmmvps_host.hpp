@@ -128,6 +128,18 @@ protected:
     PmMvps& m_pmmvps;
 };
 
+// pmmvps/filter.hpp:24-63
+class Filter {
+public:
+    explicit Filter(PmMvps& pmmvps) : m_pmmvps(pmmvps) {}
+    void init() {}
+    int run();  // filter.cpp:25-49, on the engine
+    long long m_removed[4] = {0, 0, 0, 0};  // filterOutside / filterExact / filterNeighbor / filterSmallGroups
+
+protected:
+    PmMvps& m_pmmvps;
+};
+
 // pmmvps/pmmvps.hpp:25-107
 class PmMvps {
 public:
@@ -156,6 +168,7 @@ public:
     PhotoSet m_photoSet;
     PatchManager m_patchManager;
     Propagate m_propagate;
+    Filter m_filter;
     mvs_engine* m_engine = nullptr;  // Optim + the PatchManager grids live behind this handle
     unsigned m_seed = 1;
     int m_refineSteps = 8;

@@ -97,6 +97,7 @@ def test_pmmvps_run_matches_oracle(host, small_plane_scene):
     total = 0
     for it in range(iters):
         total += o.propagate(it)["patches"]
+        o.filter()            # Filter::run (pmmvps.cpp:101)
         o.update_threshold()  # PmMvps::updateThreshold + ++m_depth (pmmvps.cpp:103-105)
     po = o.patches()
     out = np.zeros(po.shape[0] + 1000, dtype=engine.PATCH_DTYPE)
