@@ -17,9 +17,10 @@ namespace mvsdev {
 #define MVS_HASH_CAP 1024
 #define MVS_ROW_CAP 512
 #define MVS_CHECK_LDS_FLOATS (MVS_HASH_CAP + 3 * MVS_ROW_CAP)
-#define MVS_FILTER_HASH_CAP 4096
-#define MVS_FILTER_ROW_CAP 2048
-#define MVS_FILTER_LDS_FLOATS (MVS_FILTER_HASH_CAP + 3 * MVS_FILTER_ROW_CAP)
+#define MVS_FILTER_HASH_CAP 2048   // first launch over all patches: 20 KB of LDS per wave
+#define MVS_FILTER_ROW_CAP 1024
+#define MVS_FILTER2_HASH_CAP 16384 // second launch over the patches the first could not hold: 112 KB
+#define MVS_FILTER2_ROW_CAP 4096
 
 struct CheckCtx {
     const DPatch* staging;  // records created by this pass (ids >= MVS_NEWBASE)
@@ -149,6 +150,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     __syncthreads();
     const int side = 2 * margin + 1, per = side * side;
     const int ntask = c.nimg * per;
+    bool full = false;
     for (int t0 = 0; t0 < ntask; t0 += 64) {
         const int t = t0 + wc.lane;
         const int i = min(t / per, c.nimg - 1), r = t % per;
@@ -165,13 +167,14 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
                         // (id = tested and accepted, -2 - id = tested and rejected), the predicate runs once per id
                         const int id = l.live ? cx.live_ids[j] : l.fat[j].id;
                         unsigned h = (mix32((uint32_t)id)) & (HCAP - 1);
-                        bool fresh = false;
-                        for (int probe = 0; probe < HCAP; ++probe) {
+                        bool fresh = false, found = false;
+                        for (int probe = 0; probe < HCAP / 4; ++probe) {
                             const int old = atomicCAS(&table[h], -1, id);
-                            if (old == -1) { fresh = true; break; }
-                            if (old == id || old == -2 - id) break;
+                            if (old == -1) { fresh = true; found = true; break; }
+                            if (old == id || old == -2 - id) { found = true; break; }
                             h = (h + 1) & (HCAP - 1);
                         }
+                        if (!found) full = true;  // the set is (locally) full: the caller must retry with a larger one
                         if (!fresh) continue;
                         int id2;
                         const PGeo g = entry_geo(prm, cx, l, j, id2);
@@ -182,6 +185,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
         }
     }
     __syncthreads();
+    if (ballot(full)) return -1;
     // compact the set to the front of the table
     int count = 0;
     int mine[HCAP / 64];
@@ -354,6 +358,7 @@ DEV int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, C
     if (MVS_CHECK_STAGES < 2) return 0;
     int* table = reinterpret_cast<int*>(lds);
     int n = find_neighbors<MVS_HASH_CAP>(prm, wc, cx, c, table, 4.0f, 2);
+    if (n < 0) { n = 0; if (wc.lane == 0) atomicOr(overflow, 4); }
     if (MVS_CHECK_STAGES < 3) return 0;
     if (6 < n) {
         if (n > MVS_ROW_CAP) { n = MVS_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }

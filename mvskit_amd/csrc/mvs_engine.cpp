@@ -720,7 +720,16 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, st);          // filterExact
     if (int r = apply_kills(e, &rem[1])) return r;
     if (int r = filter_rebuild(e, 1)) return r;
-    mvsk_filter_neighbor(current_params(e), e->kill.p, e->error_flag.p, st);     // filterNeighbor(1)
+    {                                                                              // filterNeighbor(1)
+        if (e->uf_parent.ensure(e->pool.cap)) return MVS_ERR_HIP;                  // reused as the retry list
+        HIPCHK(hipMemsetAsync(e->misc.p + 4, 0, sizeof(unsigned long long), st));
+        int32_t* nretry = reinterpret_cast<int32_t*>(e->misc.p + 4);
+        mvsk_filter_neighbor(current_params(e), e->kill.p, e->uf_parent.p, nretry, e->error_flag.p, st);
+        int32_t nr = 0;
+        HIPCHK(hipMemcpyAsync(&nr, nretry, sizeof nr, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        mvsk_filter_neighbor_retry(current_params(e), e->kill.p, e->uf_parent.p, nr, e->error_flag.p, st);
+    }
     if (int r = apply_kills(e, &rem[2])) return r;
     if (int r = filter_rebuild(e, 1)) return r;
     {                                                                              // filterSmallGroups
@@ -744,7 +753,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     e->timing.index_ms = ms;  // whole Filter::run
     e->index_valid = false;
     if (removed4) for (int k = 0; k < 4; ++k) removed4[k] = rem[k];
-    if (herr & 4) { g_err = "mvs_engine_filter: more than 2048 neighbours of one patch (engine limit)"; return MVS_ERR_CAPACITY; }
+    if (herr & 4) { g_err = "mvs_engine_filter: more than 4096 neighbours of one patch (engine limit)"; return MVS_ERR_CAPACITY; }
     return MVS_OK;
 }
 

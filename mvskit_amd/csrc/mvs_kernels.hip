@@ -567,11 +567,17 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
     }
     if (wc.lane == 0) { atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
 }
-// Filter::filterNeighbor(1), filter.cpp:265-327: fewer than 6 neighbours, or a bad quadric fit
-__global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* kill, int32_t* overflow) {
+// Filter::filterNeighbor(1), filter.cpp:265-327: fewer than 6 neighbours, or a bad quadric fit.
+// First launch (todo == nullptr): every patch, with a hash set / row buffer that fits 2 waves per SIMD; a patch that
+// does not fit is appended to `retry`.  Second launch: only those patches, with the large configuration.
+template <int HCAP, int RCAP>
+__global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* retry, int32_t* nretry,
+                                                        int32_t* overflow) {
     extern __shared__ float s_lds[];
     __shared__ int s_dummy[1];
-    const DPatch* p = prm.pool + blockIdx.x;
+    const int64_t id = todo ? (blockIdx.x < (unsigned)ntodo ? todo[blockIdx.x] : -1) : (int64_t)blockIdx.x;
+    if (id < 0 || id >= prm.pool_n) return;
+    const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
     WaveCtx wc = make_wave_ctx(prm);
     Cand c;
@@ -579,13 +585,16 @@ __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* ki
     set_grids(prm, wc, c);
     const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy};
     int* table = reinterpret_cast<int*>(s_lds);
-    int n = find_neighbors<MVS_FILTER_HASH_CAP>(prm, wc, cx, c, table, 4.0f, 2);
-    bool reject = n < 6;
-    if (!reject) {
-        if (n > MVS_FILTER_ROW_CAP) { n = MVS_FILTER_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }
-        reject = filter_quad(prm, wc, cx, c, table, n, s_lds + MVS_FILTER_HASH_CAP) != 0;
+    const int n = find_neighbors<HCAP>(prm, wc, cx, c, table, 4.0f, 2);
+    if (n < 0 || n > RCAP) {
+        if (wc.lane == 0) {
+            if (retry) retry[atomicAdd(nretry, 1)] = (int32_t)id;
+            else atomicOr(overflow, 4);
+        }
+        return;
     }
-    if (wc.lane == 0 && reject) kill[blockIdx.x] = 1;
+    const bool reject = n < 6 || filter_quad(prm, wc, cx, c, table, n, s_lds + HCAP) != 0;
+    if (wc.lane == 0 && reject) kill[id] = 1;
 }
 // Filter::filterSmallGroups, filter.cpp:432-578, as connected components of the symmetrised relation: lock-free
 // union-find, the smaller id becomes the root.
@@ -645,7 +654,11 @@ __global__ void k_groups_count(DParams prm, int* parent, int* size) {
     if (id >= prm.pool_n || !(prm.pool[id].flags & 1)) return;
     const int r = uf_find(parent, (int)id);
     parent[id] = r;
-    atomicAdd(&size[r], 1);
+    // one giant component holds almost every patch: lanes that share the first active lane's root add once
+    const int r0 = __builtin_amdgcn_readfirstlane(r);
+    const unsigned long long same = __ballot(r == r0);
+    if (r == r0) { if ((int)(threadIdx.x & 63u) == __ffsll((long long)same) - 1) atomicAdd(&size[r0], (int)__popcll(same)); }
+    else atomicAdd(&size[r], 1);
 }
 __global__ void k_groups_kill(DParams prm, const int* parent, const int* size, int threshold, uint8_t* kill) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -790,8 +803,15 @@ void mvsk_filter_outside(const DParams& prm, uint8_t* kill, hipStream_t st) {
 void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)prm.pool_n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals);
 }
-void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* overflow, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_neighbor, dim3((unsigned)prm.pool_n), dim3(64), (size_t)MVS_FILTER_LDS_FLOATS * sizeof(float), st, prm, kill, overflow);
+void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, hipStream_t st) {
+    if (prm.pool_n <= 0) return;
+    hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP>), dim3((unsigned)prm.pool_n), dim3(64),
+                       (size_t)(MVS_FILTER_HASH_CAP + 3 * MVS_FILTER_ROW_CAP) * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow);
+}
+void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* overflow, hipStream_t st) {
+    if (ntodo <= 0) return;
+    hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP>), dim3((unsigned)ntodo), dim3(64),
+                       (size_t)(MVS_FILTER2_HASH_CAP + 3 * MVS_FILTER2_ROW_CAP) * sizeof(float), st, prm, kill, todo, ntodo, (int32_t*)nullptr, (int32_t*)nullptr, overflow);
 }
 void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st) {
     if (prm.pool_n <= 0) return;
