@@ -17,8 +17,10 @@ namespace mvsdev {
 #define MVS_HASH_CAP 1024
 #define MVS_ROW_CAP 512
 #define MVS_CHECK_LDS_FLOATS (MVS_HASH_CAP + 3 * MVS_ROW_CAP)
-#define MVS_FILTER_HASH_CAP 2048   // first launch over all patches: 20 KB of LDS per wave
-#define MVS_FILTER_ROW_CAP 1024
+#ifndef MVS_FILTER_HASH_CAP
+#define MVS_FILTER_HASH_CAP 1024   // first launch over all patches: 10 KB of LDS per wave (4 waves per SIMD)
+#define MVS_FILTER_ROW_CAP 512
+#endif
 #define MVS_FILTER2_HASH_CAP 16384 // second launch over the patches the first could not hold: 112 KB
 #define MVS_FILTER2_ROW_CAP 4096
 
