@@ -76,9 +76,28 @@ DEV float wave_sum(float x) {
     // every row of 16 now holds its row sum r0..r3 in all of its lanes.  i ^ 16 pairs rows (0,1) and (2,3), i ^ 32 the
     // halves: (r0 + r1) + (r2 + r3).  row_bcast15 into rows 1 and 3 gives r1 + r0 and r3 + r2, row_bcast31 into rows 2,3
     // gives (r3 + r2) + (r1 + r0) in row 3 -- the same sums (fp addition commutes), 3 instructions, no LDS pipeline.
-    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));  // row_bcast:15 row_mask:0xa
-    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xc, 0xf, false));  // row_bcast:31 row_mask:0xc
+    // Only lane 63 is read, so the broadcasts may run on every row (rows without a source lane add 0: bound_ctrl), which
+    // lets each step be a single v_add_f32_dpp.
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xf, 0xf, true));  // row_bcast:15
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xf, 0xf, true));  // row_bcast:31
     return rlf(x, 63);
+}
+// the same sum for two / three values at once: the steps are written interleaved so that consecutive DPP
+// instructions are independent (a DPP read of a just-written register costs two idle cycles)
+template <int CTRL> DEV float dpp0_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+#define MVS_SUM_STEP3(F, C) { const float ta = F<C>(a), tb = F<C>(b), tc = F<C>(c); a = a + ta; b = b + tb; c = c + tc; }
+#define MVS_SUM_STEP2(F, C) { const float ta = F<C>(a), tb = F<C>(b); a = a + ta; b = b + tb; }
+DEV void wave_sum3(float& a, float& b, float& c) {
+    MVS_SUM_STEP3(dpp_f, 0xB1) MVS_SUM_STEP3(dpp_f, 0x4E) MVS_SUM_STEP3(dpp_f, 0x141) MVS_SUM_STEP3(dpp_f, 0x140)
+    MVS_SUM_STEP3(dpp0_f, 0x142) MVS_SUM_STEP3(dpp0_f, 0x143)
+    a = rlf(a, 63); b = rlf(b, 63); c = rlf(c, 63);
+}
+DEV void wave_sum2(float& a, float& b) {
+    MVS_SUM_STEP2(dpp_f, 0xB1) MVS_SUM_STEP2(dpp_f, 0x4E) MVS_SUM_STEP2(dpp_f, 0x141) MVS_SUM_STEP2(dpp_f, 0x140)
+    MVS_SUM_STEP2(dpp0_f, 0x142) MVS_SUM_STEP2(dpp0_f, 0x143)
+    a = rlf(a, 63); b = rlf(b, 63);
 }
 DEV float wave_min(float x) {
     x = fminf(x, dpp_f<0xB1>(x));
@@ -290,6 +309,7 @@ struct WaveCtx {
     int lane;
     bool sample_lane;   // lane < wsize*wsize
     float fx, fy;       // this lane's sample column / row
+    float fm;           // 1 on sample lanes, 0 elsewhere
     unsigned evals, view_evals;
 };
 
@@ -326,16 +346,19 @@ DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int
 // colour - mean on sample lanes (0 elsewhere)
 DEV void tex_centre(const DParams& prm, const WaveCtx& wc, const Pending& p, float& d0, float& d1, float& d2) {
     const Texel2 q0 = p.q0, q1 = p.q1;
-    const float dx1 = p.dx1, dx0 = 1.0f - dx1, dy1 = p.dy1, dy0 = 1.0f - dy1;
+    // lanes that own no sample were sent to texel (0,0) with dx1 = dy1 = 0; fm - dy1 makes their four weights 0, so
+    // their colours are 0 without a select, and fma(-mean, fm, colour) == colour - mean on sample lanes, 0 elsewhere
+    const float dx1 = p.dx1, dx0 = 1.0f - dx1, dy1 = p.dy1, dy0 = wc.fm - dy1;
     const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
     float r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
     float g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
     float b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
-    if (!wc.sample_lane) { r = 0.0f; g = 0.0f; b = 0.0f; }
-    const float a0 = wave_sum(r) * prm.inv_sz, a1 = wave_sum(g) * prm.inv_sz, a2 = wave_sum(b) * prm.inv_sz;
-    d0 = wc.sample_lane ? r - a0 : 0.0f;
-    d1 = wc.sample_lane ? g - a1 : 0.0f;
-    d2 = wc.sample_lane ? b - a2 : 0.0f;
+    float a0 = r, a1 = g, a2 = b;
+    wave_sum3(a0, a1, a2);
+    a0 *= prm.inv_sz; a1 *= prm.inv_sz; a2 *= prm.inv_sz;
+    d0 = fma_(-a0, wc.fm, r);
+    d1 = fma_(-a1, wc.fm, g);
+    d2 = fma_(-a2, wc.fm, b);
 }
 DEV float ssd_sum(float d0, float d1, float d2) { return wave_sum(fma_(d2, d2, fma_(d1, d1, d0 * d0))); }
 // Optim::dot, optim.cpp:601-609, on centred textures, before the scale factors
@@ -391,8 +414,9 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
                 const int k = k0 + u;
                 float e0, e1, e2;
                 tex_centre(prm, wc, p[g * U + u], e0, e1, e2);
-                const float s = ssd_sum(e0, e1, e2);
-                const float dt = tex_dot_sum(d0[g][0], d0[g][1], d0[g][2], e0, e1, e2);
+                float s = fma_(e2, e2, fma_(e1, e1, e0 * e0));                        // ssd_sum
+                float dt = fma_(d0[g][2], e2, fma_(d0[g][1], e1, d0[g][0] * e0));     // tex_dot_sum
+                wave_sum2(s, dt);
                 if (k < n) {
                     okm[g] |= (unsigned)p[g * U + u].ok << k;
                     if (wc.lane == 16 * g + k) { ssd_l = s; dot_l = dt; }
@@ -935,6 +959,7 @@ DEV WaveCtx make_wave_ctx(const DParams& prm) {
     WaveCtx wc;
     wc.lane = lane_id();
     wc.sample_lane = wc.lane < prm.wsz;
+    wc.fm = wc.sample_lane ? 1.0f : 0.0f;
     wc.fx = (float)(wc.lane % prm.wsize);
     wc.fy = (float)(wc.lane / prm.wsize);
     wc.evals = 0; wc.view_evals = 0;
