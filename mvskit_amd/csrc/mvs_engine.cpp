@@ -518,6 +518,7 @@ int mvs_engine_upload_patches(mvs_engine* e, int64_t n, const mvs_patch* patches
         mvs_patch p = patches[i];
         p.nimages = std::min(p.nimages, MVS_LIST_CAP);
         if (p.nimages <= 0) continue;
+        memset(p.images + p.nimages, 0, sizeof p.images - (size_t)p.nimages);  // entries past the (truncated) list are not data
         p.nvimages = 0;
         memset(p.vimages, 0, sizeof p.vimages);
         p.tmp = std::max(0.0f, p.ncc - e->prm.nccThreshold) * p.nimages;

@@ -278,13 +278,53 @@ void PatchManager::writePatches(const string prefix, bool bExportPLY, bool bExpo
     }
 }
 void PatchManager::writePly(const vector<Ppatch>& patches, const string filename) {
+    // colour = mean over m_images of PhotoSet::getColor(image, coord, m_level) (patch_manager.cpp:565-583): the level-m_level
+    // projection (camera.cpp:91-99: rows 0,1 halved per level) and a bilinear sample (image.cpp:447-472) of the
+    // pyramid level the engine built
+    const int level = m_pmmvps.m_level, nv = m_pmmvps.m_nimages;
+    vector<vector<unsigned char> > img(nv);
+    vector<int> W(nv, 0), H(nv, 0);
+    vector<std::array<float, 12> > P(nv);
+    for (int v = 0; v < nv; ++v) {
+        const Photo& ph = m_pmmvps.m_photoSet.m_photos[v];
+        for (int i = 0; i < 12; ++i) P[v][i] = ph.m_projection[i];
+        for (int l = 0; l < level; ++l) for (int i = 0; i < 8; ++i) P[v][i] /= 2.0f;
+        if (level == 0) { img[v] = ph.m_image; W[v] = ph.m_width; H[v] = ph.m_height; continue; }
+        if (!m_pmmvps.m_engine || mvs_engine_get_pyramid(m_pmmvps.m_engine, v, level, nullptr, &W[v], &H[v]) != 0) continue;
+        img[v].resize((size_t)3 * W[v] * H[v]);
+        if (mvs_engine_get_pyramid(m_pmmvps.m_engine, v, level, img[v].data(), &W[v], &H[v]) != 0) img[v].clear();
+    }
     ofstream ofstr(filename.c_str());
     ofstr << "ply\nformat ascii 1.0\nelement vertex " << (int)patches.size()
           << "\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
              "property uchar diffuse_red\nproperty uchar diffuse_green\nproperty uchar diffuse_blue\nend_header\n";
-    for (const Ppatch& p : patches)
+    for (const Ppatch& p : patches) {
+        float colorf[3] = {0.0f, 0.0f, 0.0f};
+        int denom = 0;
+        for (int image : p->m_images) {
+            if (image < 0 || nv <= image) continue;
+            denom++;  // the reference counts every listed view (patch_manager.cpp:581)
+            if (img[image].empty()) continue;
+            const float* q = P[image].data();
+            const float* X = p->m_coord.data();
+            const float z = q[8] * X[0] + q[9] * X[1] + q[10] * X[2] + q[11] * X[3];
+            if (z <= 0.0f) continue;  // Camera::project returns (-65535, -65535): nothing to sample
+            const float x = (q[0] * X[0] + q[1] * X[1] + q[2] * X[2] + q[3] * X[3]) / z;
+            const float y = (q[4] * X[0] + q[5] * X[1] + q[6] * X[2] + q[7] * X[3]) / z;
+            if (!(x >= 0.0f && y >= 0.0f && x < (float)(W[image] - 1) && y < (float)(H[image] - 1))) continue;  // the reference reads out of bounds here
+            const int lx = (int)x, ly = (int)y;
+            const float dx1 = x - lx, dx0 = 1.0f - dx1, dy1 = y - ly, dy0 = 1.0f - dy1;
+            const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+            const unsigned char* r0 = &img[image][(size_t)3 * ((size_t)ly * W[image] + lx)];
+            const unsigned char* r1 = r0 + (size_t)3 * W[image];
+            for (int c = 0; c < 3; ++c) colorf[c] += (r0[c] * f00 + r1[c] * f01) + (r0[3 + c] * f10 + r1[3 + c] * f11);
+        }
+        int color[3] = {128, 128, 128};
+        if (denom > 0)
+            for (int c = 0; c < 3; ++c) color[c] = std::min(255, (int)floorf(colorf[c] / (float)denom + 0.5f));
         ofstr << p->m_coord[0] << ' ' << p->m_coord[1] << ' ' << p->m_coord[2] << ' ' << p->m_normal[0] << ' ' << p->m_normal[1] << ' '
-              << p->m_normal[2] << " 128 128 128\n";
+              << p->m_normal[2] << ' ' << color[0] << ' ' << color[1] << ' ' << color[2] << '\n';
+    }
 }
 
 // ------------------------------------------------------------------ Propagate
@@ -388,6 +428,9 @@ int PmMvps::run() {  // pmmvps.cpp:76-114
 }  // namespace mvshost
 
 // ------------------------------------------------------------------ C entry used by the tests: run the mirror on in-memory inputs
+static std::string g_ply_out;
+// the next mvshost_run also writes its final patches as a PLY file (PatchManager::writePly) to `path`; "" switches it off
+extern "C" void mvshost_set_ply_output(const char* path) { g_ply_out = path ? path : ""; }
 extern "C" int mvshost_run(int nviews, int width, int height, const float* P /*[n][12]*/, const unsigned char* rgb /*[n][H][W][3]*/,
                            int level, int csize, int wsize, int minImageNum, float nccThreshold, unsigned seed, int iters,
                            long long nseeds, const mvs_patch* seeds, long long cap, mvs_patch* out, long long* nout, long long* patches_total) {
@@ -419,6 +462,7 @@ extern "C" int mvshost_run(int nviews, int width, int height, const float* P /*[
     const auto& pp = pmmvps.m_patchManager.m_ppatches;
     *nout = (long long)pp.size();
     for (long long i = 0; i < std::min<long long>(cap, (long long)pp.size()); ++i) out[i] = to_record(*pp[i]);
+    if (!g_ply_out.empty()) pmmvps.m_patchManager.writePly(pp, g_ply_out);
     if (patches_total) *patches_total = total;
     return 0;
 }

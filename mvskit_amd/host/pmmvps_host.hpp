@@ -105,7 +105,7 @@ public:
     int readPatches(const int iter);
     void addPatches(const vector<Ppatch>& seeds);  // in-memory seeds
     void writePatches(const string prefix, bool bExportPLY, bool bExportPatch, bool bExportPSet);  // :499-540
-    void writePly(const vector<Ppatch>& ppatches, const string filename);                           // :542-633, colour = 128 grey
+    void writePly(const vector<Ppatch>& ppatches, const string filename);                           // :542-633, colour = mean of the views' samples
     vector<int> m_gheights, m_gwidths;
     vector<Ppatch> m_ppatches;
 

@@ -221,7 +221,8 @@ struct Scene {
     std::vector<std::vector<int>> csr_start, csr_ids, vcsr_start, vcsr_ids;
     std::vector<DestCtx> staged_cells; /* results of the last engine pass, order (view, cell) */
     int64_t cell_budget = 0;
-    double time_budget = 0.0; /* faithful schedule: stop the sweep after this many seconds (0 = off) */
+    double last_sweep_seconds = 0.0; /* engine schedule: wall time of the last colour pass's parallel loop */
+    double time_budget = 0.0; /* stop the sweep (faithful) / the colour pass (engine) after this many seconds (0 = off) */
     bool finalized = false;
     orc_counters cnt{};
 };
@@ -1657,14 +1658,29 @@ void engine_pass(Scene& s, int iter, int pass) {
     const int nthreads = std::max(1, s.cfg.nthreads);
     std::vector<orc_counters> tc(nthreads);
     for (auto& c : tc) memset(&c, 0, sizeof c);
+    /* time budget (bench.py's all-core CPU figure): destination cells not started when it runs out are skipped */
+    const auto t_start = std::chrono::steady_clock::now();
+    int stop = 0;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
     for (long j = 0; j < (long)jobs.size(); ++j) {
         int tid = 0;
 #ifdef _OPENMP
         tid = omp_get_thread_num();
 #endif
+        if (s.time_budget > 0.0) {
+            int st;
+#pragma omp atomic read
+            st = stop;
+            if (st) continue;
+            if ((j & 15) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > s.time_budget) {
+#pragma omp atomic write
+                stop = 1;
+                continue;
+            }
+        }
         dest_cell_engine(s, out[j], jobs[j].v, jobs[j].cell, iter, inc, tc[tid]);
     }
+    s.last_sweep_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     for (auto& c : tc) add_counters(s.cnt, c);
     for (auto& ctx : out) if (!ctx.staged.empty() || !ctx.kills.empty()) s.staged_cells.push_back(std::move(ctx));
 }
@@ -1864,6 +1880,7 @@ int orc_clear_patches(orc_scene* h) {
 }
 int orc_set_cell_budget(orc_scene* h, int64_t n) { h->s.cell_budget = n; return 0; }
 int orc_set_time_budget(orc_scene* h, double seconds) { h->s.time_budget = seconds; return 0; }
+double orc_last_sweep_seconds(orc_scene* h) { return h->s.last_sweep_seconds; }
 
 int orc_engine_pass(orc_scene* h, int iter, int pass, orc_counters* out) {
     Scene& s = h->s;

@@ -110,6 +110,7 @@ int orc_filter(orc_scene* s, int64_t* removed4);
 /* faithful schedule only: bound the work (for timing a sample). <=0 means unlimited. */
 int orc_set_cell_budget(orc_scene* s, int64_t max_source_cells);
 int orc_set_time_budget(orc_scene* s, double seconds);
+double orc_last_sweep_seconds(orc_scene* h); /* engine schedule: wall time of the last colour pass's parallel loop */
 
 /* view-sharded exchange (engine schedule): records created by the last pass / ids killed */
 int orc_engine_pass(orc_scene* s, int iter, int pass, orc_counters* out); /* sweep without commit */

@@ -236,6 +236,11 @@ class Oracle:
     def set_time_budget(self, seconds):
         self.L.orc_set_time_budget(self.h, float(seconds))
 
+    def last_sweep_seconds(self):
+        self.L.orc_last_sweep_seconds.restype = C.c_double
+        self.L.orc_last_sweep_seconds.argtypes = [C.c_void_p]
+        return float(self.L.orc_last_sweep_seconds(self.h))
+
     def engine_pass(self, it, p):
         c = Counters()
         self.L.orc_engine_pass(self.h, it, p, C.byref(c))

@@ -302,6 +302,15 @@ def test_two_view_config(small_plane_scene):
     assert c["patches"] > 300 and c["inserted"] > 100
 
 
+def test_variant_48_views():
+    # BASELINE.json configs[3] has 48 views: more views than a record stores (MVS_MAX_IMAGES 32) or lists keep
+    # (MVS_LIST_CAP 16), so addImages / sortImages / the per-view lanes run past both limits
+    sc = synth.make_scene(nviews=48, W=96, H=72, arc_deg=141.0, radius=4.0, kind="plane")
+    seeds = synth.make_seeds(sc, stride=6, seed=31, views=range(0, 48, 5))
+    c = _one_iteration_matches(sc, seeds, seed=6)
+    assert c["patches"] > 200 and c["inserted"] > 50
+
+
 def test_empty_pool_and_reupload(small_plane_scene):
     o, e = _pair(small_plane_scene, minImageNum=2)
     assert e.propagate(0)["patches"] == 0 and e.num_patches() == 0

@@ -18,6 +18,8 @@ def host():
     L.mvshost_option_probe.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
     L.mvshost_patch_roundtrip.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p]
     L.mvshost_camera_probe.argtypes = [C.c_char_p, C.c_void_p]
+    L.mvshost_set_ply_output.argtypes = [C.c_char_p]
+    L.mvshost_set_ply_output.restype = None
     L.mvshost_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint,
                               C.c_int, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
@@ -84,7 +86,7 @@ def test_camera_text(host, tmp_path):
 
 
 @pytest.mark.gpu
-def test_pmmvps_run_matches_oracle(host, small_plane_scene):
+def test_pmmvps_run_matches_oracle(host, small_plane_scene, tmp_path):
     import oracle_binding as ob
 
     sc = small_plane_scene
@@ -105,11 +107,34 @@ def test_pmmvps_run_matches_oracle(host, small_plane_scene):
     P = np.ascontiguousarray(sc.P, dtype=np.float32)
     img = np.ascontiguousarray(sc.images)
     sd = np.ascontiguousarray(seeds)
+    ply = tmp_path / "out.ply"
+    host.mvshost_set_ply_output(str(ply).encode())
     r = host.mvshost_run(sc.nviews, sc.W, sc.H, P.ctypes.data, img.ctypes.data, 0, 2, 7, 2, C.c_float(0.7), 9, iters, sd.shape[0], sd.ctypes.data,
                          out.shape[0], out.ctypes.data, C.byref(nout), C.byref(ptot))
+    host.mvshost_set_ply_output(b"")
     assert r == 0
     assert ptot.value == total and nout.value == po.shape[0]
     pe = out[: nout.value]
     np.testing.assert_array_equal(pe["images"], po["images"])
     np.testing.assert_allclose(pe["coord"], po["coord"], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(pe["normal"], po["normal"], rtol=0, atol=1e-3)
+
+    # PatchManager::writePly (patch_manager.cpp:542-633): vertex colour = mean over m_images of the bilinear sample at the
+    # patch's projection
+    lines = ply.read_text().split("\n")
+    body = lines[lines.index("end_header") + 1:]
+    assert int(lines[2].split()[-1]) == pe.shape[0] and len([b for b in body if b]) == pe.shape[0]
+    for k in range(0, pe.shape[0], max(1, pe.shape[0] // 50)):
+        rec = pe[k]
+        acc = np.zeros(3, np.float64)
+        for v in rec["images"][: rec["nimages"]]:
+            x = sc.P[v].astype(np.float64) @ rec["coord"].astype(np.float64)
+            fx, fy = x[0] / x[2], x[1] / x[2]
+            lx, ly = int(fx), int(fy)
+            dx, dy = fx - lx, fy - ly
+            im = sc.images[v].astype(np.float64)
+            acc += (im[ly, lx] * (1 - dx) * (1 - dy) + im[ly + 1, lx] * (1 - dx) * dy + im[ly, lx + 1] * dx * (1 - dy) + im[ly + 1, lx + 1] * dx * dy)
+        exp = np.minimum(255, np.floor(acc / rec["nimages"] + 0.5))
+        got = np.array(body[k].split()[6:9], dtype=np.float64)
+        assert np.all(np.abs(got - exp) <= 1), (k, got, exp)
+        np.testing.assert_allclose(np.array(body[k].split()[:3], dtype=np.float64), rec["coord"][:3], rtol=1e-4, atol=1e-5)
