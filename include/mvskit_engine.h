@@ -74,6 +74,7 @@ typedef struct mvs_config {
     int32_t view_begin;      /* views view_begin, view_begin+view_stride, ... are swept by this engine */
     int32_t view_stride;
     int32_t device;          /* HIP device ordinal */
+    int32_t view_propagation;/* 1 = also run the view-propagation branch the reference keeps commented out (propagate.cpp:110-120) */
     int64_t max_patches;     /* patch pool capacity (0 = 4 * total cells) */
 } mvs_config;
 

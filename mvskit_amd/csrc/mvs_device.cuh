@@ -967,8 +967,17 @@ DEV WaveCtx make_wave_ctx(const DParams& prm) {
 }
 
 // Propagate::generatePatch, propagate.cpp:220-237.  `src` is in registers (view lanes hold m_images).
-STAGE bool generate_patch(const DParams& prm, WaveCtx& wc, int* scratch, const Cand& src, F3 icoord, Cand& out) {
-    const int image = rli(src.img, 0);
+// as_view >= 0 (view propagation): the patch is re-anchored on the ray of view `as_view` and Optim::swapImage
+// (optim.cpp:385-395) makes that view the reference.
+STAGE bool generate_patch(const DParams& prm, WaveCtx& wc, int* scratch, const Cand& src, F3 icoord, Cand& out, int as_view = -1) {
+    int simg = src.img;
+    if (as_view >= 0 && rli(src.img, 0) != as_view) {
+        const unsigned long long hit = ballot(0 < wc.lane && wc.lane < src.nimg && src.img == as_view);
+        if (hit == 0ull) return false;
+        const int k = __ffsll((long long)hit) - 1, first = rli(src.img, 0);
+        simg = wc.lane == 0 ? as_view : (wc.lane == k ? first : src.img);
+    }
+    const int image = rli(simg, 0);
     const DView* vw = prm.views + image;
     const float depth = dot4(ld4(vw->oaxis), src.coord);
     const F3 nic{depth * icoord.x, depth * icoord.y, depth * icoord.z};
@@ -980,11 +989,11 @@ STAGE bool generate_patch(const DParams& prm, WaveCtx& wc, int* scratch, const C
     int ix = 0, iy = 0;
     bool keep = false;
     if (wc.lane < src.nimg) {
-        const DView* v2 = prm.views + src.img;
+        const DView* v2 = prm.views + simg;
         cell_of(prm, v2, out.coord, ix, iy);
         keep = 0 <= ix && ix < v2->gw && 0 <= iy && iy < v2->gh;
     }
-    out.img = src.img; out.gx = ix; out.gy = iy;
+    out.img = simg; out.gx = ix; out.gy = iy;
     const unsigned long long m = ballot(keep);
     const int pos = __popcll(m & ((1ull << wc.lane) - 1ull));
     __syncthreads();

@@ -100,7 +100,7 @@ void derive_params(mvs_engine* e) {  // PmMvps::init, pmmvps.cpp:32-36,54-67
     p.tau = std::min(c.minImageNum * 2, c.nviews);
     p.max_propag = c.max_propag;
     p.cap = c.max_propag * c.csize * c.csize;
-    p.depth = c.depth; p.enable_check = c.enable_check;
+    p.depth = c.depth; p.enable_check = c.enable_check; p.view_propagation = c.view_propagation ? 1 : 0;
     p.seed = c.seed; p.refine_steps = c.refine_steps; p.rd0 = c.refine_rd0; p.ra0 = c.refine_ra0;
     p.nccThreshold = c.nccThreshold;
     p.nccThresholdBefore = c.nccThreshold - 0.3f;
@@ -450,7 +450,7 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
     // jobs of one colour pass over every view (upper bound, used to size the staging bookkeeping)
     int64_t njobs_max = 0;
     for (int v = 0; v < nviews; ++v) njobs_max += (int64_t)((e->hviews[v].gw + 1) / 2) * e->hviews[v].gh;
-    const int maxstage = 2 * e->prm.cap * e->prm.max_propag;
+    const int maxstage = (e->prm.view_propagation ? 3 : 2) * e->prm.cap * e->prm.max_propag;
     if (e->job_stage.ensure(njobs_max * maxstage) || e->job_nstage.ensure(njobs_max + 2) || e->job_cnt.ensure(njobs_max + 2) ||
         e->job_base_scan.ensure(njobs_max + 2) || e->per_view.ensure(MVS_MAXVIEWS))
         return MVS_ERR_HIP;
@@ -595,7 +595,7 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     a.staging = e->staging.p; a.staging_cap = e->staging.cap;
     a.stage_counter = e->misc.p;
     a.job_stage = e->job_stage.p; a.job_nstage = e->job_nstage.p;
-    a.maxstage = 2 * e->prm.cap * e->prm.max_propag;
+    a.maxstage = (e->prm.view_propagation ? 3 : 2) * e->prm.cap * e->prm.max_propag;
     a.kill = e->kill.p;
     a.counters = e->counters.p;
     a.error_flag = e->error_flag.p;

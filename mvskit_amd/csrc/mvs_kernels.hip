@@ -305,6 +305,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
         const int g = vw->cell_base + sys[k] * gw + sxs[k];
         has |= prm.csr_cnt[g] > 0;
     }
+    if (prm.view_propagation) has |= prm.csr_cnt[vw->cell_base + cy * gw + cx] > 0;
     if (!has) return;
 
     const int tstride = (prm.wsz + 3) & ~3;
@@ -322,13 +323,19 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
     int ns = 0;  // staged records of this job
     const float icx = (float)(prm.csize * (2 * cx + 1) - 1) / 2.0f, icy = (float)(prm.csize * (2 * cy + 1) - 1) / 2.0f;
 
-    for (int sidx = 0; sidx < 2; ++sidx) {
-        if (sxs[sidx] < 0 || gw <= sxs[sidx] || sys[sidx] < 0 || gh <= sys[sidx]) continue;
-        const int g = vw->cell_base + sys[sidx] * gw + sxs[sidx];
+    // sources: the cell above/below, the cell beside (propagate.cpp:104-108), and -- view propagation, the branch the
+    // reference keeps commented out (propagate.cpp:110-120) -- this cell's own list: a patch of another reference view
+    // that is listed here proposes itself with view v as the reference
+    const int nsrc = prm.view_propagation ? 3 : 2;
+    for (int sidx = 0; sidx < nsrc; ++sidx) {
+        const int scx = sidx < 2 ? sxs[sidx] : cx, scy = sidx < 2 ? sys[sidx] : cy;
+        if (scx < 0 || gw <= scx || scy < 0 || gh <= scy) continue;
+        const int g = vw->cell_base + scy * gw + scx;
         const CellEntry* se = prm.csr_fat + prm.csr_start[g];
         const int sn = prm.csr_cnt[g];
+        const int as_view = sidx == 2 ? v : -1;
         for (int n = 0; n < sn; ++n) {
-            if (se[n].ref != v) continue;
+            if ((se[n].ref == v) == (sidx == 2)) continue;
             const DPatch* sp = prm.pool + se[n].id;
             const int srcslot = sidx * prm.cap + n;
             // ---- Propagate::propagatePatch, propagate.cpp:153-213
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
                 {
                     Cand src;  // loaded per trial: its registers are free again during the refinement
                     load_cand(sp, wc, src);
-                    if (!generate_patch(prm, wc, s_scratch, src, ic, c)) continue;
+                    if (!generate_patch(prm, wc, s_scratch, src, ic, c, as_view)) continue;
                 }
                 ++n_cand;
                 if (np >= prm.cap && c.ncc < worst_ncc) { ++n_pref; continue; }

@@ -54,7 +54,7 @@ struct DView {
 
 // Kernel-constant parameters (Option + PmMvps thresholds, pmmvps.cpp:18-68).
 struct DParams {
-    int32_t nviews, level, csize, wsize, wsz, minImageNum, tau, cap, max_propag, depth, enable_check;
+    int32_t nviews, level, csize, wsize, wsz, minImageNum, tau, cap, max_propag, depth, enable_check, view_propagation;
     uint32_t seed;
     int32_t refine_steps;
     float rd0, ra0;

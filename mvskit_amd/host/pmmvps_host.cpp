@@ -365,7 +365,7 @@ int PmMvps::createEngine(float maxAngle, float quad) {
     cfg.nviews = m_nimages; cfg.level = m_level; cfg.csize = m_csize; cfg.wsize = m_wsize;
     cfg.minImageNum = m_minImageNumThreshold; cfg.nccThreshold = m_nccThreshold;
     cfg.maxAngleThreshold = maxAngle; cfg.quadThreshold = quad;
-    cfg.depth = 0; cfg.seed = m_seed; cfg.refine_steps = m_refineSteps;
+    cfg.depth = 0; cfg.seed = m_seed; cfg.refine_steps = m_refineSteps; cfg.view_propagation = m_viewPropagation;
     cfg.enable_check = 1;  // Optim::check from m_depth >= 2 (optim.cpp:292)
     int r = mvs_engine_create(&cfg, &m_engine);
     if (r != 0) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }

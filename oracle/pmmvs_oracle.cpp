@@ -1324,15 +1324,26 @@ int post_process(const Scene& s, Patch& p, const DestCtx* ctx, orc_counters* cnt
 }
 
 /* Propagate::generatePatch, propagate.cpp:220-237 */
-bool generate_patch(const Scene& s, const Patch& src, const V3& icoord, Patch& out, orc_counters* cnt) {
+/* as_image >= 0 (view propagation, trash/propagate_view_propagation_simiar_to_original.cpp:125-147): the patch is
+ * re-anchored on the ray of view `as_image` instead of its reference view -- depth along that view's optical axis,
+ * back-projection through that view -- and Optim::swapImage (optim.cpp:385-395) makes it the reference view. */
+bool generate_patch(const Scene& s, const Patch& src, const V3& icoord, Patch& out, orc_counters* cnt, int as_image = -1) {
     out = Patch();
-    const int image = src.img[0];
+    int images[LISTCAP];
+    for (int i = 0; i < src.nimg; ++i) images[i] = src.img[i];
+    if (as_image >= 0 && images[0] != as_image) {
+        int k = -1;
+        for (int i = 1; i < src.nimg; ++i) if (images[i] == as_image) { k = i; break; }
+        if (k < 0) return false;
+        std::swap(images[0], images[k]);
+    }
+    const int image = images[0];
     const View& vw = s.views[image];
     const float depth = dot4(vw.oaxis, src.coord);
     const V3 nic{depth * icoord.x, depth * icoord.y, depth * icoord.z};
     out.coord = unproject(vw, nic, s.cfg.level);
     out.normal = src.normal;
-    set_grids_images(s, out, src.img, src.nimg);
+    set_grids_images(s, out, images, src.nimg);
     if (out.nimg == 0) return false;
     out.ncc = compute_ncc(s, out, cnt);
     return true;
@@ -1557,7 +1568,8 @@ void insert_sorted(const Scene& s, DestCtx& ctx, int id) {
 }
 
 /* Propagate::propagatePatch on the live list of one destination cell, propagate.cpp:126-218 */
-void propagate_patch_engine(const Scene& s, DestCtx& ctx, int src, int image, int index, int iter, int srcslot, orc_counters& cnt) {
+void propagate_patch_engine(const Scene& s, DestCtx& ctx, int src, int image, int index, int iter, int srcslot, orc_counters& cnt,
+                            int as_image = -1) {
     const int gw = s.views[image].gw;
     const int cx = index % gw, cy = index / gw;
     const V3 icoord{(s.cfg.csize * (2 * cx + 1) - 1) / 2.0f, (s.cfg.csize * (2 * cy + 1) - 1) / 2.0f, 1.0f};
@@ -1571,13 +1583,13 @@ void propagate_patch_engine(const Scene& s, DestCtx& ctx, int src, int image, in
             const float a = rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], 0) * s.cfg.csize;
             const float b = rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], 1) * s.cfg.csize;
             const V3 nic{icoord.x + a, icoord.y + b, 1.0f};
-            if (!generate_patch(s, srcp, nic, cand, &cnt)) continue;
+            if (!generate_patch(s, srcp, nic, cand, &cnt, as_image)) continue;
             cnt.candidates++;
         } else {
             worst = ctx.list[s.cap - 1];
             const Patch& wp = get_patch(s, worst, &ctx);
             const V3 ic = project(s.views[image], wp.coord, s.cfg.level);
-            if (!generate_patch(s, srcp, ic, cand, &cnt)) continue;
+            if (!generate_patch(s, srcp, ic, cand, &cnt, as_image)) continue;
             cnt.candidates++;
             if (cand.ncc < wp.ncc) { cnt.prefiltered++; continue; }
         }
@@ -1623,6 +1635,19 @@ void dest_cell_engine(const Scene& s, DestCtx& ctx, int image, int index, int it
             propagate_patch_engine(s, ctx, sid, image, index, iter, sidx * s.cap + n, cnt);
         }
     }
+    /* View propagation -- the branch the reference keeps commented out (propagate.cpp:110-120), after the design in
+     * trash/propagate_view_propagation_simiar_to_original.cpp:95-147: a patch of another reference view that is listed
+     * in this cell (it is visible in `image` and projects here) proposes itself with `image` as the reference view.
+     * Same trial logic as the spatial sources (fill / replace-worst, pre/refine/post); sources are this cell's list
+     * as it stood at the start of the pass. */
+    if (s.cfg.view_propagation) {
+        const int b = s.csr_start[image][index], e = s.csr_start[image][index + 1];
+        for (int n = 0; n < e - b; ++n) {
+            const int sid = s.csr_ids[image][b + n];
+            if (s.pool[sid].img[0] == image) continue;
+            propagate_patch_engine(s, ctx, sid, image, index, iter, 2 * s.cap + n, cnt, image);
+        }
+    }
 }
 
 void add_counters(orc_counters& a, const orc_counters& b) {
@@ -1651,6 +1676,7 @@ void engine_pass(Scene& s, int iter, int pass) {
                 const int sc = sy[k] * vw.gw + sx[k];
                 has = s.csr_start[v][sc + 1] > s.csr_start[v][sc];
             }
+            if (s.cfg.view_propagation) { const int sc = cy * vw.gw + cx; has = has || s.csr_start[v][sc + 1] > s.csr_start[v][sc]; }
             if (has) jobs.push_back({v, cy * vw.gw + cx});
         }
     }

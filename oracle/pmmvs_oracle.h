@@ -65,6 +65,7 @@ typedef struct orc_config {
     int32_t view_begin;   /* engine schedule: views [view_begin, view_end) with stride are swept */
     int32_t view_stride;
     int32_t nthreads;     /* engine schedule only: OpenMP threads over destination cells */
+    int32_t view_propagation; /* engine schedule only: the disabled branch of propagate.cpp:110-120 (see dest_cell_engine) */
 } orc_config;
 
 typedef struct orc_counters {

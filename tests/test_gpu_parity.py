@@ -311,6 +311,27 @@ def test_variant_48_views():
     assert c["patches"] > 200 and c["inserted"] > 50
 
 
+def test_view_propagation_matches_oracle(small_multi_scene):
+    """the view-propagation branch the reference keeps commented out (propagate.cpp:110-120, design in
+    trash/propagate_view_propagation_simiar_to_original.cpp:95-147), as an option of the engine schedule."""
+    sc = small_multi_scene
+    seeds = synth.make_seeds(sc, stride=4, seed=23, views=[0, sc.nviews // 2])
+    o, e = _pair(sc, seed=5, view_propagation=1)
+    o0, _ = _pair(sc, seed=5)
+    for x in (o, e, o0):
+        (x.add_patches if hasattr(x, "add_patches") else x.upload_patches)(seeds)
+    for it in range(2):
+        co, ce = o.propagate(it), e.propagate(it)
+        assert co == ce, (it, co, ce)
+        c0 = o0.propagate(it)
+    assert co["patches"] > 1.3 * c0["patches"]  # patches of other views proposing themselves: more candidates per pass
+    po, pe = o.patches(), e.patches()
+    assert po.shape == pe.shape
+    np.testing.assert_array_equal(po["images"], pe["images"])
+    np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+    np.testing.assert_allclose(pe["normal"], po["normal"], rtol=0, atol=REL_TOL)
+
+
 def test_empty_pool_and_reupload(small_plane_scene):
     o, e = _pair(small_plane_scene, minImageNum=2)
     assert e.propagate(0)["patches"] == 0 and e.num_patches() == 0

@@ -233,3 +233,26 @@ def test_refinement_reduces_depth_error(small_plane_scene):
         after.append(abs(float(q["coord"][2])))
     assert len(before) > 20
     assert np.median(after) < 0.35 * np.median(before)
+
+
+def test_view_propagation_option(small_plane_scene):
+    """Engine schedule, view_propagation = 1 (the branch propagate.cpp:110-120 keeps commented out): patches listed in
+    a cell under another reference view propose themselves there.  More candidates than the spatial sweep alone, the
+    spatial candidates unchanged in number at the first pass, and the result independent of the thread count."""
+    sc = small_plane_scene
+    seeds = synth.make_seeds(sc, stride=4, seed=3, views=[0])
+    res = {}
+    for vp, nt in ((0, 1), (1, 1), (1, 4)):
+        o = ob.Oracle(sc.nviews, level=0, minImageNum=2, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64, enable_check=0, seed=2,
+                      nthreads=nt, view_propagation=vp)
+        o.set_scene(sc)
+        o.add_patches(seeds)
+        c = o.propagate(0)
+        res[(vp, nt)] = (c, o.patches())
+        o.close()
+    c0, c1 = res[(0, 1)][0], res[(1, 1)][0]
+    assert c1["candidates"] > c0["candidates"] and c1["inserted"] > c0["inserted"]
+    # seeds all have reference view 0: without the option the other views' sweeps have no source at all
+    assert set(np.unique(res[(0, 1)][1]["images"][:, 0])) <= set(np.unique(res[(1, 1)][1]["images"][:, 0]))
+    assert res[(1, 1)][0] == res[(1, 4)][0]
+    np.testing.assert_array_equal(res[(1, 1)][1]["coord"], res[(1, 4)][1]["coord"])
