@@ -131,3 +131,36 @@ class DeviceExchange:
             engine.commit_device(allrec.data_ptr(), allrec.shape[0], allkill.data_ptr(), allkill.shape[0])
             totals = c if totals is None else {k: totals[k] + c[k] for k in c}
         return totals
+
+
+class HostStaged:
+    """Adapter giving an `Engine` the host-side pass/export/commit interface `sharded_propagate_host` drives (the
+    exchange then runs over any torch.distributed backend on CPU tensors, e.g. gloo when several ranks share one GPU)."""
+
+    def __init__(self, engine, device):
+        import torch
+
+        self.torch, self.e, self.device = torch, engine, device
+
+    def engine_pass(self, it, p):
+        return self.e.engine_pass(it, p)
+
+    def export_new(self):
+        torch = self.torch
+        n_new, n_kill, per_view = self.e.export_counts()
+        rec = torch.zeros(max(n_new, 1), RECORD_BYTES, dtype=torch.uint8, device=self.device)
+        kil = torch.full((max(n_kill, 1),), -1, dtype=torch.int32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        self.e.export_device(rec.data_ptr(), rec.shape[0], kil.data_ptr(), kil.shape[0])
+        self._kills = kil[:n_kill].cpu().numpy()
+        return rec[:n_new].cpu().numpy(), per_view
+
+    def export_kills(self):
+        return self._kills
+
+    def commit(self, recs, kills):
+        torch = self.torch
+        r = torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(-1, RECORD_BYTES).copy()).to(self.device)
+        k = torch.from_numpy(np.ascontiguousarray(kills, dtype=np.int32).copy()).to(self.device)
+        torch.cuda.synchronize(self.device)
+        self.e.commit_device(r.data_ptr(), r.shape[0], k.data_ptr(), k.shape[0])
