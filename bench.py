@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--refine-steps", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--filter", action="store_true", help="BASELINE config 5: run Filter::run (filter.cpp:25-49) after every iteration, inside the timed region")
+    ap.add_argument("--force-exchange", action="store_true", help="rehearsal: run the N>1 code path (RCCL exchange) with a world of 1")
     ap.add_argument("--scene-cache", default=os.path.join("/tmp", "mvskit_scene_cache"))
     return ap.parse_args()
 
@@ -124,11 +125,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="nccl", device_id=device, rank=0, world_size=1)
 
     from mvskit_amd import engine as eng
     from mvskit_amd.dist import DeviceExchange
@@ -146,12 +151,12 @@ def main():
         log(f"scene ready: {sc.nviews} views {sc.W}x{sc.H}, {seeds.shape[0]} seeds")
     e.set_scene(sc)
     e.upload_patches(seeds)
-    ex = DeviceExchange(device) if world > 1 else None
+    ex = DeviceExchange(device) if (world > 1 or args.force_exchange) else None
 
     def step(it):
         ts = time.perf_counter()
         c = ex.propagate(e, it) if ex else e.propagate(it)
-        t = e.timing()
+        t = dict(ex.last_timing) if ex else e.timing()
         if args.filter:
             tf = time.perf_counter()
             c["filter_removed"] = e.filter()
@@ -171,14 +176,15 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     patches = view_evals = evals = 0
-    sweep_ms = index_ms = commit_ms = 0.0
-    launches = 0
+    sweep_ms = index_ms = commit_ms = exchange_ms = 0.0
+    launches = exchange_bytes = local_view_evals = 0
     for _ in range(args.steps):
         c, t = step(it)
         it += 1
         patches += c["patches"]; view_evals += c["view_evals"]; evals += c["evals"]
-        if ex is None:
-            sweep_ms += t["sweep_ms"]; index_ms += t["index_ms"]; commit_ms += t["commit_ms"]; launches += t["sweep_launches"]
+        sweep_ms += t["sweep_ms"]; index_ms += t["index_ms"]; commit_ms += t["commit_ms"]; launches += t["sweep_launches"]
+        exchange_ms += t.get("exchange_ms", 0.0); exchange_bytes += t.get("exchange_bytes", 0)
+        local_view_evals += c["view_evals"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -215,8 +221,8 @@ def main():
             "view_evals": view_evals,
             "pool_alive": n_alive,
         }
-        if ex is None and sweep_ms > 0:
-            alg = view_evals * ALG_BYTES_PER_VIEW_EVAL
+        if sweep_ms > 0:
+            alg = local_view_evals * ALG_BYTES_PER_VIEW_EVAL  # rank 0's own launches (= the whole job at N = 1)
             ach = alg / (sweep_ms * 1e-3) / 1e9
             traffic = None
             prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -229,12 +235,16 @@ def main():
                                "kernel": "k_sweep", "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
                                "algorithmic_bytes_per_launch": alg / max(launches, 1),
                                "index_ms": index_ms, "commit_ms": commit_ms, "sweep_ms": sweep_ms}
+            if ex is not None:
+                out["roofline"]["rank"] = 0
+                out["exchange"] = {"ms": exchange_ms, "bytes_gathered_per_rank": exchange_bytes, "collective": "all_gather_into_tensor (RCCL)",
+                                   "note": "counts + padded 128-byte patch records + kill ids, after each colour pass"}
         if world == 1 and args.cpu_seconds > 0:
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(args, sc, seeds)
         print(json.dumps(out))
     e.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

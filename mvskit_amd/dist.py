@@ -103,10 +103,17 @@ class DeviceExchange:
     def propagate(self, engine, iter_index: int):
         """One Propagate::run(iter) on the rank's views; returns this rank's counters."""
         torch, dist, world = self.torch, self.dist, self.world
+        import time
+
         nviews = engine.cfg.nviews
         totals = None
+        self.last_timing = {"index_ms": 0.0, "sweep_ms": 0.0, "commit_ms": 0.0, "sweep_launches": 0, "exchange_ms": 0.0, "exchange_bytes": 0}
         for p in range(2):
             c = engine.engine_pass(iter_index, p)
+            t = engine.timing()
+            for k in ("index_ms", "sweep_ms", "sweep_launches"):
+                self.last_timing[k] += t[k]
+            t_ex = time.perf_counter()
             n_new, n_kill, per_view = engine.export_counts()
             mine = torch.zeros(nviews + 2, dtype=torch.int64, device=self.device)
             mine[:nviews] = torch.as_tensor(per_view.astype(np.int64), device=self.device)
@@ -128,7 +135,10 @@ class DeviceExchange:
             allkill = torch.cat([gkil[r, : int(counts_h[r, nviews + 1])] for r in range(world)]) if max_kill else torch.zeros(0, dtype=torch.int32, device=self.device)
             allrec, allkill = allrec.contiguous(), allkill.contiguous()
             torch.cuda.synchronize(self.device)  # the engine commits on its own HIP stream
+            self.last_timing["exchange_ms"] += 1000.0 * (time.perf_counter() - t_ex)
+            self.last_timing["exchange_bytes"] += int(grec.numel() + 4 * gkil.numel() + 8 * counts.numel())
             engine.commit_device(allrec.data_ptr(), allrec.shape[0], allkill.data_ptr(), allkill.shape[0])
+            self.last_timing["commit_ms"] += engine.timing()["commit_ms"]
             totals = c if totals is None else {k: totals[k] + c[k] for k in c}
         return totals
 
