@@ -15,7 +15,7 @@ namespace mvsdev {
 // Optim::check (inside the sweep) uses the small configuration; Filter::filterNeighbor, which sees the untrimmed lists
 // of every patch, the large one.
 #define MVS_HASH_CAP 1024
-#define MVS_ROW_CAP 512
+#define MVS_ROW_CAP 448   // 4 KB hash set + 3 x 448 rows + the 768 B of static LDS = 10 KB: 16 waves per CU
 #define MVS_CHECK_LDS_FLOATS (MVS_HASH_CAP + 3 * MVS_ROW_CAP)
 #ifndef MVS_FILTER_HASH_CAP
 #define MVS_FILTER_HASH_CAP 1024   // first launch over all patches: 10 KB of LDS per wave (4 waves per SIMD)

@@ -48,8 +48,20 @@ DEV unsigned long long ballot(bool p) { return __ballot(p); }
 
 DEV float dot4(F4 a, F4 b) { return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x))); }
 DEV float dot3(F3 a, F3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
-DEV float norm4(F4 a) { return sqrtf(dot4(a, a)); }
-DEV float norm3(F3 a) { return sqrtf(dot3(a, a)); }
+// Correctly rounded square root (== the oracle's sqrtf) for zero, normal and infinite arguments: v_sqrt_f32 is within one
+// ulp, and the residuals of its two neighbours (one fma each) decide which of the three is the rounded root.  This is
+// the compiler's own IEEE expansion without the rescaling of arguments below 2^-96, which this path never produces
+// (squared lengths and texture variances), and at half its instruction count.
+DEV float sqrt_rn(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+    const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
+    s = rd <= 0.0f ? dn : s;
+    s = ru > 0.0f ? up : s;
+    return s;
+}
+DEV float norm4(F4 a) { return sqrt_rn(dot4(a, a)); }
+DEV float norm3(F3 a) { return sqrt_rn(dot3(a, a)); }
 DEV F4 sub4(F4 a, F4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
 DEV F4 add4(F4 a, F4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 DEV F4 mul4(F4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
@@ -138,12 +150,23 @@ DEV float pm_cosf(float x) {
     if (a <= 3.0f * MVS_PIO4) return k_sinf((MVS_PIO2_HI - a) + MVS_PIO2_LO);
     return -k_cosf(MVS_PI - a);
 }
+// sin and cos of one angle: the same three ranges, kernels and reduced arguments as pm_sinf / pm_cosf, evaluated once
+// and selected (lanes of one wave usually fall in different ranges, so the branches of the two calls would all run)
+DEV void pm_sincosf(float x, float& s, float& c) {
+    const float a = fabsf(x);
+    const bool r0 = a <= MVS_PIO4, r1 = a <= 3.0f * MVS_PIO4;
+    const float t = r0 ? a : (r1 ? (MVS_PIO2_HI - a) + MVS_PIO2_LO : MVS_PI - a);
+    const float ks = k_sinf(t), kc = k_cosf(t);
+    const float sr = (r0 || !r1) ? ks : kc;
+    s = x < 0.0f ? -sr : sr;
+    c = r0 ? kc : (r1 ? ks : -kc);
+}
 DEV float pm_asinf(float x) {
     float a = fabsf(x);
     if (a > 1.0f) a = 1.0f;
     float z, xx;
     bool flag = a > 0.5f;
-    if (flag) { z = 0.5f * (1.0f - a); xx = sqrtf(z); }
+    if (flag) { z = 0.5f * (1.0f - a); xx = sqrt_rn(z); }
     else { z = a * a; xx = a; }
     float p = 4.2163199048e-2f * z + 2.4181311049e-2f;
     p = p * z + 4.5470025998e-2f;
@@ -154,8 +177,8 @@ DEV float pm_asinf(float x) {
     return x < 0.0f ? -r : r;
 }
 DEV float pm_acosf(float x) {
-    if (x < -0.5f) return MVS_PI - 2.0f * pm_asinf(sqrtf(0.5f * (1.0f + x)));
-    if (x > 0.5f) return 2.0f * pm_asinf(sqrtf(0.5f * (1.0f - x)));
+    if (x < -0.5f) return MVS_PI - 2.0f * pm_asinf(sqrt_rn(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * pm_asinf(sqrt_rn(0.5f * (1.0f - x)));
     return MVS_PIO2_HI - pm_asinf(x);
 }
 DEV float pm_atanf(float v) {
@@ -367,7 +390,7 @@ DEV float tex_dot_sum(float a0, float a1, float a2, float b0, float b1, float b2
 }
 // second half of Optim::normalize, optim.cpp:932-939, on whatever lanes hold an ssd: 1 / msd
 DEV float inv_msd(const DParams& prm, float ssd) {
-    float msd = sqrtf(ssd * prm.inv_3sz);
+    float msd = sqrt_rn(ssd * prm.inv_3sz);
     if (msd == 0.0f) msd = 1.0f;
     return 1.0f / msd;
 }
@@ -397,6 +420,7 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
         okm[g] |= (unsigned)pr[g].ok;
         if (wc.lane == 16 * g) ssd_l = s;
     }
+#pragma unroll 2
     for (int k0 = 1; k0 < n; k0 += U) {
         Pending p[NS];
 #pragma unroll
@@ -665,7 +689,9 @@ DEV void decode(const DParams& prm, const RefineCtx& rc, float x0, float x1, flo
     const float t = rc.dscale * x0;
     coord = {fma_(t, rc.ray.x, rc.center.x), fma_(t, rc.ray.y, rc.center.y), fma_(t, rc.ray.z, rc.center.z), fma_(t, rc.ray.w, rc.center.w)};
     const float angle1 = x1 * rc.ascale, angle2 = x2 * rc.ascale;
-    const float s1 = pm_sinf(angle1), c1 = pm_cosf(angle1), s2 = pm_sinf(angle2), c2 = pm_cosf(angle2);
+    float s1, c1, s2, c2;
+    pm_sincosf(angle1, s1, c1);
+    pm_sincosf(angle2, s2, c2);
     const float fx = s1 * c2, fy = s2, fz = -c1 * c2;
     const DView* vw = prm.views + rc.ref;
     normal = {fma_(vw->zaxis[0], fz, fma_(vw->yaxis[0], fy, vw->xaxis[0] * fx)),
@@ -675,15 +701,25 @@ DEV void decode(const DParams& prm, const RefineCtx& rc, float x0, float x1, flo
 // Optim::cost_func (optim.cpp:401-468) for up to three proposals at once: lane 16*g + i decodes proposal g
 // (x0..x2 hold that lane's proposal), builds the patch axes and the frame of view i; then each proposal is
 // evaluated in turn.  imgx = m_images replicated into every group of 16 lanes.
-DEV double cost_of_group(const DParams& prm, const WaveCtx& wc, unsigned okm, float val_l, int g, int sz, int minimum) {
-    if (!(okm & 1u)) return 2.0;
-    double ans = 0.0;
-    int denom = 0;
+DEV void sum_of_group(const WaveCtx& wc, unsigned okm, float val_l, int g, int sz, double& ans, int& denom) {
+    ans = 0.0;
+    denom = 0;
     for (int i = 1; i < sz; ++i) {
         if (!((okm >> i) & 1u)) continue;
         ans += (double)rlf(val_l, 16 * g + i);
         denom++;
     }
+}
+DEV double rld(double x, int l) {
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)rli((int)(b & 0xffffffffll), l), hi = (unsigned)rli((int)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+DEV double cost_of_group(const DParams& prm, const WaveCtx& wc, unsigned okm, float val_l, int g, int sz, int minimum) {
+    if (!(okm & 1u)) return 2.0;
+    double ans;
+    int denom;
+    sum_of_group(wc, okm, val_l, g, sz, ans, denom);
     if (denom < minimum - 1) return 2.0;
     return ans / (double)denom;
 }
@@ -703,9 +739,18 @@ DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
         unsigned okm[3];
         eval_core<3, 1>(prm, wc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
-        f0 = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
-        f1 = cost_of_group(prm, wc, okm[1], val_l, 1, sz, minimum);
-        f2 = cost_of_group(prm, wc, okm[2], val_l, 2, sz, minimum);
+        // the three means: one fp64 division for all of them (lane j divides the sums of proposal j)
+        double a0, a1, a2;
+        int d0, d1, d2;
+        sum_of_group(wc, okm[0], val_l, 0, sz, a0, d0);
+        sum_of_group(wc, okm[1], val_l, 1, sz, a1, d1);
+        sum_of_group(wc, okm[2], val_l, 2, sz, a2, d2);
+        const double num = wc.lane == 1 ? a1 : (wc.lane == 2 ? a2 : a0);
+        const int den = wc.lane == 1 ? d1 : (wc.lane == 2 ? d2 : d0);
+        const double q = num / (double)den;
+        f0 = ((okm[0] & 1u) && d0 >= minimum - 1) ? rld(q, 0) : 2.0;
+        f1 = ((okm[1] & 1u) && d1 >= minimum - 1) ? rld(q, 1) : 2.0;
+        f2 = ((okm[2] & 1u) && d2 >= minimum - 1) ? rld(q, 2) : 2.0;
     } else {
         wc.evals += 1;
         unsigned okm[1];

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64) void k_fill_ncc(DParams prm, unsigned long long
 DEV bool rank_before(float na, int a, float nb, int b) { return (na != nb) ? (na > nb) : (a < b); }
 
 #ifndef MVS_SWEEP_WAVES
-#define MVS_SWEEP_WAVES 3  // waves per SIMD the register allocator is asked to fit (k_sweep)
+#define MVS_SWEEP_WAVES 4  // waves per SIMD the register allocator is asked to fit: 128 VGPRs, and 10 KB of LDS per wave (k_sweep)
 #endif
 __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, SweepArgs a) {
     __shared__ int s_scratch[192];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
     if (prm.view_propagation) has |= prm.csr_cnt[vw->cell_base + cy * gw + cx] > 0;
     if (!has) return;
 
-    const int tstride = (prm.wsz + 3) & ~3;
+    const int tstride = prm.wsz;  // odd for 7x7 / 5x5 windows: the lane-per-pair reads of setRefImage fall in distinct banks
     unsigned n_cand = 0, n_pref = 0, n_patch = 0, n_f0 = 0, n_f1 = 0, n_ins = 0, n_rep = 0;
     // live list of this cell as view-lane arrays: lane k holds entry k (sorted: ncc desc, id asc)
     int L_id = -1;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
     c.nimg = min((int)__popcll(pm), MVS_LISTCAP);
     c.img = s_scratch[64 + wc.lane];
     if (prm.minImageNum <= c.nimg) {
-        const int tstride = (prm.wsz + 3) & ~3;
+        const int tstride = prm.wsz;  // odd for 7x7 / 5x5 windows: the lane-per-pair reads of setRefImage fall in distinct banks
         set_ref_image(prm, wc, s_texs, tstride, c);
         store_lists(p, wc, c);
     } else {
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, co
     const int64_t i = blockIdx.x;
     if (i >= n) return;
     WaveCtx wc = make_wave_ctx(prm);
-    const int tstride = (prm.wsz + 3) & ~3;
+    const int tstride = prm.wsz;  // odd for 7x7 / 5x5 windows: the lane-per-pair reads of setRefImage fall in distinct banks
     if (op == 5) {  // MVS_PROBE_MATH
         if (wc.lane == 0) {
             const float x = in_f[i];
@@ -773,14 +773,16 @@ void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_fill_ncc, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, evals);
 }
 size_t mvsk_sweep_lds_bytes(const DParams& prm) {
-    const size_t texs = (size_t)MVS_LISTCAP * 3 * ((prm.wsz + 3) & ~3) * sizeof(float);  // setRefImage textures
+    const size_t texs = (size_t)MVS_LISTCAP * 3 * prm.wsz * sizeof(float);  // setRefImage textures: 9408 B at wsize 7
     const size_t chk = (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float);                      // Optim::check hash set + rows
     return texs > chk ? texs : chk;
 }
 void mvsk_sweep(const DParams& prm, const SweepArgs& a, hipStream_t st) {
     if (a.njobs <= 0) return;
     const int64_t chunk = (a.njobs + 7) / 8;
-    hipLaunchKernelGGL(k_sweep, dim3((unsigned)(chunk * 8)), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, a);
+    // development knob: MVS_SWEEP_LDS_PAD=<bytes> raises the block's LDS allocation, i.e. lowers the waves per SIMD
+    static const size_t pad = getenv("MVS_SWEEP_LDS_PAD") ? (size_t)atol(getenv("MVS_SWEEP_LDS_PAD")) : 0;
+    hipLaunchKernelGGL(k_sweep, dim3((unsigned)(chunk * 8)), dim3(64), mvsk_sweep_lds_bytes(prm) + pad, st, prm, a);
 }
 void mvsk_commit_count(const SweepArgs& a, int32_t* cnt, hipStream_t st) { hipLaunchKernelGGL(k_commit_count, dim3(nblk(a.njobs, 256)), dim3(256), 0, st, a, cnt); }
 void mvsk_commit_copy(const SweepArgs& a, const int32_t* base, DPatch* dst, int64_t dst_cap, int32_t* per_view, int keep_key, hipStream_t st) {

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .build import LIB_PATH
+from . import build
 from .synth import MAX_IMAGES, PATCH_DTYPE  # noqa: F401  (PATCH_DTYPE mirrors mvs_patch)
 
 PROBE_NCC, PROBE_PREPROCESS, PROBE_REFINE, PROBE_POSTPROCESS, PROBE_COST, PROBE_MATH = range(6)
@@ -63,6 +63,7 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    LIB_PATH = os.environ.get("MVS_ENGINE_LIB", build.LIB_PATH)  # development: A/B timing of two builds on one box
     if not os.path.exists(LIB_PATH):
         raise EngineError(f"{LIB_PATH} is missing: run `python -m mvskit_amd.build` (the engine has no CPU fallback)")
     try:
