@@ -15,11 +15,13 @@ namespace mvsdev {
 // Optim::check (inside the sweep) uses the small configuration; Filter::filterNeighbor, which sees the untrimmed lists
 // of every patch, the large one.
 #define MVS_HASH_CAP 1024
+#ifndef MVS_ROW_CAP
 #define MVS_ROW_CAP 448   // 4 KB hash set + 3 x 448 rows + the 768 B of static LDS = 10 KB: 16 waves per CU
+#endif
 #define MVS_CHECK_LDS_FLOATS (MVS_HASH_CAP + 3 * MVS_ROW_CAP)
 #ifndef MVS_FILTER_HASH_CAP
 #define MVS_FILTER_HASH_CAP 1024   // first launch over all patches: 10 KB of LDS per wave (4 waves per SIMD)
-#define MVS_FILTER_ROW_CAP 512
+#define MVS_FILTER_ROW_CAP 448      // the same limits as Optim::check: the oracle picks the table size by one rule
 #endif
 #define MVS_FILTER2_HASH_CAP 16384 // second launch over the patches the first could not hold: 112 KB
 #define MVS_FILTER2_ROW_CAP 4096
@@ -28,7 +30,16 @@ struct CheckCtx {
     const DPatch* staging;  // records created by this pass (ids >= MVS_NEWBASE)
     int live_view, live_cell, live_n;
     const int* live_ids;    // LDS: the destination cell's current list
+    unsigned long long* st; // diagnostic build (-DMVS_STAGE_TIMING): DCounters::stage, else unused
 };
+#ifdef MVS_STAGE_TIMING
+#define CK_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
+#define CK_ADD(k) { const unsigned long long t1_ = CK_NOW(); if (cx.st && wc.lane == 0) atomicAdd(cx.st + (k), t1_ - ck_t); ck_t = t1_; }
+#define CK_BEGIN() unsigned long long ck_t = CK_NOW();
+#else
+#define CK_ADD(k)
+#define CK_BEGIN()
+#endif
 
 DEV const DPatch* patch_ptr(const DParams& prm, const CheckCtx& cx, int id) {
     return id >= MVS_NEWBASE ? cx.staging + (id - MVS_NEWBASE) : prm.pool + id;
@@ -119,7 +130,28 @@ DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
 }
 
 // PatchManager::findNeighbors, patch_manager.cpp:671-728 (scale 4, margin 2 as Optim::check calls it).
-// Leaves the sorted unique ids in `table[0..count)` (LDS, MVS_HASH_CAP ints) and returns count.
+// Leaves the neighbour ids in `table[0..count)` (LDS, HCAP ints) and returns count, or -1 when the set does not fit.
+//
+// A patch shows up in the cells of several views, so the ids met in the nimg x (2 margin + 1)^2 cell lists go through
+// a hash set first and the predicate runs once per id.  The set is an ORDERED linear-probing table (Amble & Knuth):
+// a probe that meets a smaller key takes its slot and carries the smaller key on, which with atomicMax needs no lock
+// and leaves -- whatever the order of the insertions -- the one layout in which every key sits behind larger keys only:
+// the layout of inserting the keys in descending order with plain linear probing.  The slot order of that layout is the
+// order in which filterQuad sums over the neighbours; the oracle rebuilds it the simple way, so no sort is needed here.
+//   phase A: every lane takes one (view, cell) pair, loads the ids of its two lists four at a time and inserts them;
+//   phase B: the table is streamed 64 slots at a time: record gather (next chunk's loads in flight), predicate,
+//            ballot compaction of the accepted ids to the front of the table.
+#define MVS_SET_EMPTY (-1)
+DEV bool set_insert(int* table, unsigned mask, int k) {
+    unsigned p = mix32((uint32_t)k) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        const int old = atomicMax(&table[p], k);
+        if (old == k || old == MVS_SET_EMPTY) return true;
+        if (old < k) k = old;  // took the slot of a smaller key: carry that one on
+        p = (p + 1) & mask;
+    }
+    return false;
+}
 template <int HCAP>
 DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin) {
     const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
@@ -147,9 +179,11 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
         unit *= (float)prm.csize;
     }
     const float thr = prm.neighborThreshold * scale;
+    CK_BEGIN()
     __syncthreads();
-    for (int t = wc.lane; t < HCAP; t += 64) table[t] = -1;
+    for (int t = wc.lane; t < HCAP; t += 64) table[t] = MVS_SET_EMPTY;
     __syncthreads();
+    // ---- phase A
     const int side = 2 * margin + 1, per = side * side;
     const int ntask = c.nimg * per;
     bool full = false;
@@ -164,62 +198,45 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
                 const int cell = yt * vw->gw + xt;
                 for (int kind = 0; kind < 2; ++kind) {
                     const ListRef l = cell_span(prm, cx, kind, v, cell);
-                    for (int j = 0; j < l.n; ++j) {
-                        // a patch shows up in the cells of several views: the set remembers every id it has seen
-                        // (id = tested and accepted, -2 - id = tested and rejected), the predicate runs once per id
-                        const int id = l.live ? cx.live_ids[j] : l.fat[j].id;
-                        unsigned h = (mix32((uint32_t)id)) & (HCAP - 1);
-                        bool fresh = false, found = false;
-                        for (int probe = 0; probe < HCAP / 4; ++probe) {
-                            const int old = atomicCAS(&table[h], -1, id);
-                            if (old == -1) { fresh = true; found = true; break; }
-                            if (old == id || old == -2 - id) { found = true; break; }
-                            h = (h + 1) & (HCAP - 1);
+                    for (int j0 = 0; j0 < l.n; j0 += 4) {
+                        int id[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int j = min(j0 + q, l.n - 1);
+                            id[q] = l.live ? cx.live_ids[j] : l.fat[j].id;
                         }
-                        if (!found) full = true;  // the set is (locally) full: the caller must retry with a larger one
-                        if (!fresh) continue;
-                        int id2;
-                        const PGeo g = entry_geo(prm, cx, l, j, id2);
-                        if (!is_neighbor_radius(prm, me, g, unit, thr, radius)) table[h] = -2 - id;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (j0 + q < l.n && !set_insert(table, HCAP - 1, id[q])) full = true;
                     }
                 }
             }
         }
     }
     __syncthreads();
+    CK_ADD(9)
     if (ballot(full)) return -1;
-    // compact the set to the front of the table
-    int count = 0;
-    int mine[HCAP / 64];
-#pragma unroll
-    for (int k = 0; k < HCAP / 64; ++k) mine[k] = table[k * 64 + wc.lane];
-    __syncthreads();
-#pragma unroll
+    // ---- phase B
+    int count = 0, visited = 0;
+    int v_next = table[wc.lane];
+    PGeo g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));
     for (int k = 0; k < HCAP / 64; ++k) {
-        const bool has = mine[k] >= 0;
-        const unsigned long long m = ballot(has);
-        if (has) table[count + __popcll(m & ((1ull << wc.lane) - 1ull))] = mine[k];
-        count += __popcll(m);
-    }
-    __syncthreads();
-    // bitonic sort ascending of table[0..count), padded with INT_MAX to a power of two
-    int npad = 64;
-    while (npad < count) npad <<= 1;
-    for (int t = count + wc.lane; t < npad; t += 64) table[t] = INT_MAX;
-    __syncthreads();
-    for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = wc.lane; t < npad; t += 64) {
-                const int ixj = t ^ j;
-                if (ixj > t) {
-                    const int a = table[t], b = table[ixj];
-                    const bool up = (t & k) == 0;
-                    if ((a > b) == up) { table[t] = b; table[ixj] = a; }
-                }
-            }
-            __syncthreads();
+        const int v_cur = v_next;
+        const PGeo g_cur = g_next;
+        if (k + 1 < HCAP / 64) {
+            v_next = table[(k + 1) * 64 + wc.lane];
+            g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));  // an empty slot reads record 0: harmless, unused
         }
+        const bool seen = v_cur >= 0;
+        const bool acc = seen && is_neighbor_radius(prm, me, g_cur, unit, thr, radius);
+        visited += (int)__popcll(ballot(seen));
+        const unsigned long long m = ballot(acc);
+        if (acc) table[count + __popcll(m & ((1ull << wc.lane) - 1ull))] = v_cur;  // count + rank <= 64 k + lane: already read
+        count += (int)__popcll(m);
     }
+    __syncthreads();
+    CK_ADD(10)
+    if (visited > HCAP - HCAP / 8) return -1;  // beyond 7/8 full the oracle's table-size rule picks the next size
     return count;
 }
 
@@ -354,7 +371,9 @@ DEV int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, C
 #ifndef MVS_CHECK_STAGES
 #define MVS_CHECK_STAGES 3  // timing experiments only: 1 = gain, 2 = + neighbours, 3 = everything
 #endif
+    CK_BEGIN()
     const float gain = compute_gain(prm, wc, cx, c);
+    CK_ADD(8)
     c.tmp = gain;
     if (gain < 0.0f) { c.nimg = 0; return 1; }
     if (MVS_CHECK_STAGES < 2) return 0;
@@ -364,7 +383,10 @@ DEV int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, C
     if (MVS_CHECK_STAGES < 3) return 0;
     if (6 < n) {
         if (n > MVS_ROW_CAP) { n = MVS_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }
-        if (filter_quad(prm, wc, cx, c, table, n, lds + MVS_HASH_CAP)) { c.nimg = 0; return 1; }
+        CK_BEGIN()
+        const int fq = filter_quad(prm, wc, cx, c, table, n, lds + MVS_HASH_CAP);
+        CK_ADD(11)
+        if (fq) { c.nimg = 0; return 1; }
     }
     return 0;
 }

@@ -366,6 +366,42 @@ DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int
     p.dx1 = sx - (float)lx; p.dy1 = sy - (float)ly;
     return p;
 }
+// The same with the frames published in LDS (eval_core): three uniform-address ds_read_b128 (broadcasts, issued on
+// the LDS pipe) replace ten v_readlane_b32 on the VALU, which is the unit this kernel saturates.
+#ifndef MVS_FRAME_LDS
+#define MVS_FRAME_LDS 1
+#endif
+#define MVS_FRAME_LDS_BYTES (48 * 48)  // frame lanes 0..47, 12 dwords each; the start of the kernel's dynamic LDS
+extern __shared__ float4 mvs_dyn_lds4[];
+DEV void frames_publish(const WaveCtx& wc, const Frame& f, int nlanes) {
+    __syncthreads();  // whatever used the region before (setRefImage textures, Optim::check rows) is done
+    if (wc.lane < nlanes) {
+        float4* d = mvs_dyn_lds4 + 3 * wc.lane;
+        d[0] = make_float4(f.tlx, f.tly, f.dxx, f.dxy);
+        d[1] = make_float4(f.dyx, f.dyy, __int_as_float(f.w), __int_as_float(f.ok));
+        d[2] = make_float4(__int_as_float((int)f.img_lo), __int_as_float((int)f.img_hi), 0.0f, 0.0f);
+    }
+    __syncthreads();
+}
+DEV Pending tex_issue_lds(const DParams& prm, const WaveCtx& wc, int e) {
+    Pending p;
+    const float4* s = mvs_dyn_lds4 + 3 * e;
+    const float4 A = s[0], B = s[1];
+    const float2 Cc = *reinterpret_cast<const float2*>(s + 2);
+    p.ok = __float_as_int(B.w);
+    const int W = __float_as_int(B.z);
+    typedef const __attribute__((address_space(1))) uint32_t* GlobalTexels;
+    const unsigned long long base = ((unsigned long long)(unsigned)__float_as_int(Cc.y) << 32) | (unsigned long long)(unsigned)__float_as_int(Cc.x);
+    const float sx = wc.sample_lane ? fma_(B.x, wc.fy, fma_(A.z, wc.fx, A.x)) : 0.0f;
+    const float sy = wc.sample_lane ? fma_(B.y, wc.fy, fma_(A.w, wc.fx, A.y)) : 0.0f;
+    const int lx = (int)sx, ly = (int)sy;
+    const unsigned long long a0 = base + 4ull * (unsigned long long)(unsigned)(ly * W + lx);
+    const GlobalTexels t0 = (GlobalTexels)a0, t1 = (GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)W);
+    p.q0.a = t0[0]; p.q0.b = t0[1];
+    p.q1.a = t1[0]; p.q1.b = t1[1];
+    p.dx1 = sx - (float)lx; p.dy1 = sy - (float)ly;
+    return p;
+}
 // colour - mean on sample lanes (0 elsewhere)
 DEV void tex_centre(const DParams& prm, const WaveCtx& wc, const Pending& p, float& d0, float& d1, float& d2) {
     const Texel2 q0 = p.q0, q1 = p.q1;
@@ -407,20 +443,26 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
     float d0[NP][3];
     float ssd_l = 1.0f, dot_l = 0.0f;
     Pending pr[NP], pn[NS];
+    unsigned okv[NP];  // per-lane copies of the (uniform) masks: the ok flags come back from LDS in vector registers
+#if MVS_FRAME_LDS
+    frames_publish(wc, f, 16 * NP);
+#define TEX_ISSUE(e) tex_issue_lds(prm, wc, e)
+#else
+#define TEX_ISSUE(e) tex_issue(prm, wc, f, e)
+#endif
 #pragma unroll
-    for (int g = 0; g < NP; ++g) { okm[g] = 0u; pr[g] = tex_issue(prm, wc, f, 16 * g); }
+    for (int g = 0; g < NP; ++g) { okv[g] = 0u; pr[g] = TEX_ISSUE(16 * g); }
 #pragma unroll
     for (int g = 0; g < NP; ++g)
 #pragma unroll
-        for (int u = 0; u < U; ++u) pn[g * U + u] = tex_issue(prm, wc, f, 16 * g + min(1 + u, n - 1));
+        for (int u = 0; u < U; ++u) pn[g * U + u] = TEX_ISSUE(16 * g + min(1 + u, n - 1));
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
         tex_centre(prm, wc, pr[g], d0[g][0], d0[g][1], d0[g][2]);
         const float s = ssd_sum(d0[g][0], d0[g][1], d0[g][2]);
-        okm[g] |= (unsigned)pr[g].ok;
+        okv[g] |= (unsigned)pr[g].ok;
         if (wc.lane == 16 * g) ssd_l = s;
     }
-#pragma unroll 2
     for (int k0 = 1; k0 < n; k0 += U) {
         Pending p[NS];
 #pragma unroll
@@ -429,7 +471,7 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
 #pragma unroll
             for (int g = 0; g < NP; ++g)
 #pragma unroll
-                for (int u = 0; u < U; ++u) pn[g * U + u] = tex_issue(prm, wc, f, 16 * g + min(k0 + U + u, n - 1));
+                for (int u = 0; u < U; ++u) pn[g * U + u] = TEX_ISSUE(16 * g + min(k0 + U + u, n - 1));
         }
 #pragma unroll
         for (int g = 0; g < NP; ++g)
@@ -442,13 +484,16 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
                 float dt = fma_(d0[g][2], e2, fma_(d0[g][1], e1, d0[g][0] * e0));     // tex_dot_sum
                 wave_sum2(s, dt);
                 if (k < n) {
-                    okm[g] |= (unsigned)p[g * U + u].ok << k;
+                    okv[g] |= (unsigned)p[g * U + u].ok << k;
                     if (wc.lane == 16 * g + k) { ssd_l = s; dot_l = dt; }
                 }
             }
     }
     // the metric's work count: views that sampled; nothing counts when the reference view itself was rejected
     // (Optim::cost_func / computeINCC / setINCCs return before looking at the others, optim.cpp:448,657,725)
+#undef TEX_ISSUE
+#pragma unroll
+    for (int g = 0; g < NP; ++g) okm[g] = (unsigned)rfl((int)okv[g]);
 #pragma unroll
     for (int g = 0; g < NP; ++g) wc.view_evals += (okm[g] & 1u) ? (unsigned)__popc(okm[g]) : 0u;
     const float inv_l = inv_msd(prm, ssd_l);

@@ -15,7 +15,7 @@
 #include "mvs_types.h"
 
 static_assert(sizeof(mvs_patch) == sizeof(DPatch), "mvs_patch and DPatch must be the same bytes");
-static_assert(MVS_LIST_CAP == MVS_LISTCAP && MVS_MAX_IMAGES == MVS_MAXI, "limits out of sync");
+static_assert(MVS_LIST_CAP >= MVS_LISTCAP && MVS_MAX_IMAGES == MVS_MAXI, "limits out of sync");
 
 namespace {
 thread_local std::string g_err;
@@ -623,6 +623,16 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
         out->fail0 = (int64_t)hc.fail0; out->fail1 = (int64_t)hc.fail1; out->inserted = (int64_t)hc.inserted; out->replaced = (int64_t)hc.replaced;
         out->evals = (int64_t)(hc.evals + fill[0]); out->view_evals = (int64_t)(hc.view_evals + fill[1]); out->trimmed = (int64_t)trimmed;
     }
+#ifdef MVS_STAGE_TIMING
+    {
+        static const char* nm[8] = {"wave", "generate", "pre", "refine", "post", "check", "stage", "prologue"};
+        fprintf(stderr, "[stage cycles]");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hc.stage[k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
+        static const char* nm2[4] = {"gain", "search", "sort", "quad"};
+        for (int k = 0; k < 4; ++k) fprintf(stderr, " %s %.1f%%", nm2[k], 100.0 * (double)hc.stage[8 + k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
+        fprintf(stderr, "  (wave cycles %.3e)\n", (double)hc.stage[0]);
+    }
+#endif
     if (herr & 3) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
     if (herr & 4) { g_err = "mvs_engine_pass: Optim::check met more than 512 neighbours of one patch (engine limit)"; return MVS_ERR_CAPACITY; }
     return MVS_OK;

@@ -281,6 +281,15 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
     extern __shared__ float s_texs[];
     // XCD-aware job order: blocks are dealt round-robin over the 8 XCDs, so block b works on job
     // (b % 8) * chunk + b / 8 and each XCD's L2 sees one contiguous band of cells.
+#ifdef MVS_STAGE_TIMING
+#define ST_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
+#define ST_ADD(k, t0) { const unsigned long long t1_ = ST_NOW(); st_acc[k] += t1_ - (t0); (t0) = t1_; }
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = ST_NOW();
+    unsigned long long st_t = st_begin;
+#else
+#define ST_ADD(k, t0)
+#endif
     const int64_t chunk = (a.njobs + 7) / 8;
     const int64_t job = (int64_t)(blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
     if (job >= a.njobs) return;
@@ -340,6 +349,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
             const int srcslot = sidx * prm.cap + n;
             // ---- Propagate::propagatePatch, propagate.cpp:153-213
             for (int it = 0; it < prm.max_propag; ++it) {
+                ST_ADD(7, st_t)
                 const int np = L_n;
                 const uint32_t k0 = (uint32_t)a.iter, k1 = (uint32_t)v, k2 = (uint32_t)cell, k3 = (uint32_t)(srcslot * 16 + it);
                 Cand c;
@@ -359,20 +369,29 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
                 {
                     Cand src;  // loaded per trial: its registers are free again during the refinement
                     load_cand(sp, wc, src);
-                    if (!generate_patch(prm, wc, s_scratch, src, ic, c, as_view)) continue;
+                    const bool gen_ok = generate_patch(prm, wc, s_scratch, src, ic, c, as_view);
+                    ST_ADD(1, st_t)
+                    if (!gen_ok) continue;
                 }
                 ++n_cand;
                 if (np >= prm.cap && c.ncc < worst_ncc) { ++n_pref; continue; }
                 ++n_patch;
-                if (pre_process(prm, wc, s_scratch, c) == -1) { ++n_f0; continue; }
+                const int pre_r = pre_process(prm, wc, s_scratch, c);
+                ST_ADD(2, st_t)
+                if (pre_r == -1) { ++n_f0; continue; }
                 refine_patch(prm, wc, c, k0, k1, k2, k3);
-                if (post_process(prm, wc, s_scratch, s_texs, tstride, c) == -1) { ++n_f1; continue; }
+                ST_ADD(3, st_t)
+                const int post_r = post_process(prm, wc, s_scratch, s_texs, tstride, c);
+                ST_ADD(4, st_t)
+                if (post_r == -1) { ++n_f1; continue; }
                 if (prm.depth >= 2 && prm.enable_check) {  // Optim::check, optim.cpp:292
                     __syncthreads();
                     if (wc.lane < MVS_CAPMAX) s_scratch[wc.lane] = L_id;  // publish the live list of this cell
                     __syncthreads();
-                    const CheckCtx cx{a.staging, v, cell, L_n, s_scratch};
-                    if (check_patch(prm, wc, cx, c, s_texs, a.error_flag)) { ++n_f1; continue; }
+                    const CheckCtx cx{a.staging, v, cell, L_n, s_scratch, a.counters->stage};
+                    const int chk_r = check_patch(prm, wc, cx, c, s_texs, a.error_flag);
+                    ST_ADD(5, st_t)
+                    if (chk_r) { ++n_f1; continue; }
                 }
                 // staging slot for the accepted patch
                 unsigned long long slot64 = 0;
@@ -404,6 +423,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
                     if (wc.lane == pos) { L_id = nid; L_ncc = c.ncc; }
                     ++L_n;
                 }
+                ST_ADD(6, st_t)
             }
         }
     }
@@ -419,6 +439,10 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
         if (n_rep) atomicAdd(&C->replaced, (unsigned long long)n_rep);
         if (wc.evals) atomicAdd(&C->evals, (unsigned long long)wc.evals);
         if (wc.view_evals) atomicAdd(&C->view_evals, (unsigned long long)wc.view_evals);
+#ifdef MVS_STAGE_TIMING
+        st_acc[0] = ST_NOW() - st_begin;
+        for (int k = 0; k < 8; ++k) if (st_acc[k]) atomicAdd(&C->stage[k], st_acc[k]);
+#endif
     }
 }
 
@@ -524,7 +548,7 @@ __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kil
     load_cand(p, wc, c);
     set_grids(prm, wc, c);
     set_vgrids(prm, wc, c);
-    const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy};
+    const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, nullptr};
     const float gain = compute_gain(prm, wc, cx, c);
     if (wc.lane == 0 && gain < 0.0f) kill[blockIdx.x] = 1;
 }
@@ -590,7 +614,7 @@ __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* ki
     Cand c;
     load_cand(p, wc, c);
     set_grids(prm, wc, c);
-    const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy};
+    const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, nullptr};
     int* table = reinterpret_cast<int*>(s_lds);
     const int n = find_neighbors<HCAP>(prm, wc, cx, c, table, 4.0f, 2);
     if (n < 0 || n > RCAP) {
@@ -770,7 +794,7 @@ void mvsk_map_extract(const DParams& prm, int view, int kind, const unsigned lon
     hipLaunchKernelGGL(k_map_extract, dim3(nblk(ncells, 256)), dim3(256), 0, st, prm, view, kind, sel, depth, normal, ids, ncells);
 }
 void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_fill_ncc, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, evals);
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_fill_ncc, dim3((unsigned)prm.pool_n), dim3(64), MVS_FRAME_LDS_BYTES, st, prm, evals);
 }
 size_t mvsk_sweep_lds_bytes(const DParams& prm) {
     const size_t texs = (size_t)MVS_LISTCAP * 3 * prm.wsz * sizeof(float);  // setRefImage textures: 9408 B at wsize 7
@@ -830,6 +854,6 @@ void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint
     hipLaunchKernelGGL(k_groups_kill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size, threshold, kill);
 }
 void mvsk_probe(const DParams& prm, int op, int64_t n, const DPatch* in, const float* in_f, DPatch* out, float* out_f, int32_t* out_i, hipStream_t st) {
-    if (n > 0 && op == 2) { hipLaunchKernelGGL(k_probe_refine, dim3((unsigned)n), dim3(64), 0, st, prm, n, in, out); return; }
+    if (n > 0 && op == 2) { hipLaunchKernelGGL(k_probe_refine, dim3((unsigned)n), dim3(64), MVS_FRAME_LDS_BYTES, st, prm, n, in, out); return; }
     if (n > 0) hipLaunchKernelGGL(k_probe, dim3((unsigned)n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, op, n, in, in_f, out, out_f, out_i);
 }

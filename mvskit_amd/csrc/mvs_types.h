@@ -4,7 +4,9 @@
 
 #define MVS_WAVE 64
 #define MVS_MAXLEV 7       // level (<=4) + 3 pyramid levels (pmmvps.cpp:36)
+#ifndef MVS_LISTCAP
 #define MVS_LISTCAP 16     // m_images / m_vimages are truncated to 16 views
+#endif
 #define MVS_MAXI 32        // storage in the record
 #define MVS_MAXVIEWS 64    // one lane per view in the per-view phases
 #define MVS_CAPMAX 32      // MAX_NUM_OF_PATCHES = max_propag * csize^2 <= 32
@@ -79,6 +81,10 @@ struct DParams {
 
 struct DCounters {
     unsigned long long candidates, prefiltered, patches, fail0, fail1, inserted, replaced, evals, view_evals, trimmed;
+    // diagnostic build (-DMVS_STAGE_TIMING): wave cycles (s_memtime) per stage of the sweep, summed over waves:
+    // 0 whole wave, 1 generatePatch, 2 preProcess, 3 refinePatch, 4 postProcess, 5 check, 6 staging/insert, 7 prologue
+    // 8 computeGain, 9 findNeighbors search, 10 compaction + sort, 11 filterQuad
+    unsigned long long stage[16];
 };
 
 // Arguments of one sweep launch (one colour pass over the owned views).

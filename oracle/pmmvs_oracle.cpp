@@ -989,7 +989,32 @@ float compute_radius(const Scene& s, const Patch& p) {
 }
 
 /* PatchManager::findNeighbors, patch_manager.cpp:671-728 */
+/* Engine arithmetic (ORC_SUM_TREE64): the order in which filterQuad's sums run over the neighbours.  The GPU finds
+ * the neighbours through a hash set of every id it meets in the scanned cell lists (`visited`), an ordered
+ * linear-probing table (each key sits behind larger keys only), whose layout does not depend on the order of the
+ * insertions: it is the layout of inserting the keys in descending order with plain linear probing.  The accepted ids
+ * are taken in slot order.  Table size: 1024 slots while at most 7/8 of them are visited and at most 448 ids are
+ * accepted (mvs_check.cuh: MVS_HASH_CAP, MVS_ROW_CAP), else 16384 (Filter::filterNeighbor's second launch). */
+void engine_neighbor_order(std::vector<int> visited, std::vector<int>& nb /* sorted unique in, slot order out */) {
+    std::sort(visited.begin(), visited.end());
+    visited.erase(std::unique(visited.begin(), visited.end()), visited.end());
+    size_t cap = (visited.size() <= 896 && nb.size() <= 448) ? 1024 : 16384;
+    while (visited.size() * 8 > cap * 7) cap *= 2; /* beyond the engine's limits (it reports an error there) */
+    std::vector<int> table(cap, -1);
+    for (size_t k = visited.size(); k-- > 0;) {
+        size_t p = mix32((uint32_t)visited[k]) & (cap - 1);
+        while (table[p] != -1) p = (p + 1) & (cap - 1);
+        table[p] = visited[k];
+    }
+    std::vector<int> out;
+    out.reserve(nb.size());
+    for (size_t p = 0; p < cap; ++p)
+        if (table[p] >= 0 && std::binary_search(nb.begin(), nb.end(), table[p])) out.push_back(table[p]);
+    nb.swap(out);
+}
+
 void find_neighbors(const Scene& s, const Patch& p, std::vector<int>& nb, float scale, int margin, const DestCtx* ctx) {
+    std::vector<int> visited;
     const float radius = (float)(1.5 * margin * compute_radius(s, p));
     float unit = 0.0f;
     for (int i = 0; i < p.nimg; ++i) unit += get_unit(s, p.img[i], p.coord);
@@ -1007,14 +1032,17 @@ void find_neighbors(const Scene& s, const Patch& p, std::vector<int>& nb, float 
                 const int cell = yt * vw.gw + xt;
                 for (int kind = 0; kind < 2; ++kind) {
                     const Span l = cell_list(s, kind, v, cell, ctx);
-                    for (int j = 0; j < l.n; ++j)
+                    for (int j = 0; j < l.n; ++j) {
+                        visited.push_back(l.p[j]);
                         if (is_neighbor_radius(s, p, get_patch(s, l.p[j], ctx), unit, s.neighborThreshold * scale, radius)) nb.push_back(l.p[j]);
+                    }
                 }
             }
         }
     }
     std::sort(nb.begin(), nb.end());
     nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+    if (s.cfg.sum_mode == ORC_SUM_TREE64) engine_neighbor_order(visited, nb);
 }
 
 /* Filter::ortho, filter.cpp:394-409 */
