@@ -97,35 +97,57 @@ DEV PGeo entry_geo(const DParams& prm, const CheckCtx& cx, const ListRef& l, int
     return {{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
 }
 
-// Filter::computeGain, filter.cpp:108-146
-DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c) {
+// Filter::computeGain, filter.cpp:108-146.  One lane per (view, list entry) pair -- a list holds at most
+// MAX_NUM_OF_PATCHES entries after the trim, so one or two rounds of 64 pairs cover all views -- and the per-view maxima
+// (a maximum does not depend on the order) are collected with LDS atomics.  tmp: MVS_LISTCAP ints of LDS.
+DEV void gain_part(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, const PGeo& me, bool visible_part, int* tmp, float& gain) {
+    const int nv = visible_part ? c.nvimg : c.nimg;
+    if (nv == 0) return;
+    int ln = 0, lcell = 0, lview = 0;  // view lane i: its cell list
+    float pdepth = 0.0f;
+    if (wc.lane < nv) {
+        lview = visible_part ? c.vimg : c.img;
+        const DView* vw = prm.views + lview;
+        lcell = (visible_part ? c.vgy : c.gy) * vw->gw + (visible_part ? c.vgx : c.gx);
+        ln = cell_span(prm, cx, 0, lview, lcell).n;
+        if (visible_part) pdepth = dot4(ld4(vw->oaxis), c.coord);
+    }
+    int off = ln;  // inclusive prefix over the view lanes, then exclusive
+#pragma unroll
+    for (int d = 1; d < MVS_LISTCAP; d <<= 1) { const int t = __shfl_up(off, d); if (wc.lane >= d) off += t; }
+    const int total = rli(off, nv - 1);
+    off -= ln;
+    __syncthreads();
+    if (wc.lane < MVS_LISTCAP) tmp[wc.lane] = 0;  // +0.0f
+    __syncthreads();
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + wc.lane;
+        int owner = 0;  // the last view lane whose first pair is <= t
+        for (int i = 1; i < nv; ++i) owner += (rli(off, i) <= t) ? 1 : 0;
+        const int j = t - __shfl(off, owner);
+        const int v = __shfl(lview, owner), cell = __shfl(lcell, owner);
+        const float pd = __shfl(pdepth, owner);
+        if (t < total) {
+            const ListRef l = cell_span(prm, cx, 0, v, cell);
+            int id;
+            const PGeo g = entry_geo(prm, cx, l, j, id);
+            bool counts = true;
+            if (visible_part) counts = pd < dot4(ld4((prm.views + v)->oaxis), g.coord);
+            if (counts && !is_neighbor(prm, me, g, prm.neighborThreshold1)) {
+                const float val = g.ncc - prm.nccThreshold;
+                if (val > 0.0f) atomicMax(&tmp[owner], __float_as_int(val));  // positive floats order like their bit patterns
+            }
+        }
+    }
+    __syncthreads();
+    const float vmax = wc.lane < MVS_LISTCAP ? __int_as_float(tmp[wc.lane]) : 0.0f;
+    for (int i = 0; i < nv; ++i) gain -= rlf(vmax, i);
+}
+DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* tmp) {
     const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
     float gain = score2(c, prm.nccThreshold);
-    float maxp = 0.0f;
-    if (wc.lane < c.nimg) {
-        const int v = c.img;
-        const ListRef l = cell_span(prm, cx, 0, v, c.gy * (prm.views + v)->gw + c.gx);
-        for (int j = 0; j < l.n; ++j) {
-            int id;
-            const PGeo g = entry_geo(prm, cx, l, j, id);
-            if (!is_neighbor(prm, me, g, prm.neighborThreshold1)) maxp = fmaxf(maxp, g.ncc - prm.nccThreshold);
-        }
-    }
-    for (int i = 0; i < c.nimg; ++i) gain -= rlf(maxp, i);
-    maxp = 0.0f;
-    if (wc.lane < c.nvimg) {
-        const int v = c.vimg;
-        const DView* vw = prm.views + v;
-        const float pdepth = dot4(ld4(vw->oaxis), c.coord);
-        const ListRef l = cell_span(prm, cx, 0, v, c.vgy * vw->gw + c.vgx);
-        for (int j = 0; j < l.n; ++j) {
-            int id;
-            const PGeo g = entry_geo(prm, cx, l, j, id);
-            const float bdepth = dot4(ld4(vw->oaxis), g.coord);
-            if (pdepth < bdepth && !is_neighbor(prm, me, g, prm.neighborThreshold1)) maxp = fmaxf(maxp, g.ncc - prm.nccThreshold);
-        }
-    }
-    for (int i = 0; i < c.nvimg; ++i) gain -= rlf(maxp, i);
+    gain_part(prm, wc, cx, c, me, false, tmp, gain);
+    gain_part(prm, wc, cx, c, me, true, tmp, gain);
     return gain;
 }
 
@@ -216,22 +238,29 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     __syncthreads();
     CK_ADD(9)
     if (ballot(full)) return -1;
-    // ---- phase B
-    int count = 0, visited = 0;
-    int v_next = table[wc.lane];
-    PGeo g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));
+    // ---- phase B: the visited ids to the front of the table (slot order kept), then record gather + predicate over
+    // that dense list, the next 64 records in flight while the current ones are tested
+    int visited = 0;
     for (int k = 0; k < HCAP / 64; ++k) {
+        const int v = table[k * 64 + wc.lane];
+        const unsigned long long m = ballot(v >= 0);
+        if (v >= 0) table[visited + __popcll(m & ((1ull << wc.lane) - 1ull))] = v;  // visited + rank <= 64 k + lane: already read
+        visited += (int)__popcll(m);
+    }
+    __syncthreads();
+    int count = 0;
+    int v_next = wc.lane < visited ? table[wc.lane] : -1;
+    PGeo g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));  // lanes past the end read record 0: harmless, unused
+    for (int b0 = 0; b0 < visited; b0 += 64) {
         const int v_cur = v_next;
         const PGeo g_cur = g_next;
-        if (k + 1 < HCAP / 64) {
-            v_next = table[(k + 1) * 64 + wc.lane];
-            g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));  // an empty slot reads record 0: harmless, unused
+        if (b0 + 64 < visited) {
+            v_next = b0 + 64 + wc.lane < visited ? table[b0 + 64 + wc.lane] : -1;
+            g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));
         }
-        const bool seen = v_cur >= 0;
-        const bool acc = seen && is_neighbor_radius(prm, me, g_cur, unit, thr, radius);
-        visited += (int)__popcll(ballot(seen));
+        const bool acc = v_cur >= 0 && is_neighbor_radius(prm, me, g_cur, unit, thr, radius);
         const unsigned long long m = ballot(acc);
-        if (acc) table[count + __popcll(m & ((1ull << wc.lane) - 1ull))] = v_cur;  // count + rank <= 64 k + lane: already read
+        if (acc) table[count + __popcll(m & ((1ull << wc.lane) - 1ull))] = v_cur;  // count + rank <= b0 + lane: already read
         count += (int)__popcll(m);
     }
     __syncthreads();
@@ -372,7 +401,7 @@ DEV int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, C
 #define MVS_CHECK_STAGES 3  // timing experiments only: 1 = gain, 2 = + neighbours, 3 = everything
 #endif
     CK_BEGIN()
-    const float gain = compute_gain(prm, wc, cx, c);
+    const float gain = compute_gain(prm, wc, cx, c, reinterpret_cast<int*>(lds));  // the set's LDS is free until findNeighbors
     CK_ADD(8)
     c.tmp = gain;
     if (gain < 0.0f) { c.nimg = 0; return 1; }

@@ -541,6 +541,7 @@ __global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive
 // Filter::filterOutside, filter.cpp:51-106: gain < 0 -> removed
 __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kill) {
     __shared__ int s_dummy[1];
+    __shared__ int s_gain[MVS_LISTCAP];
     const DPatch* p = prm.pool + blockIdx.x;
     if (!(p->flags & 1)) return;
     WaveCtx wc = make_wave_ctx(prm);
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kil
     set_grids(prm, wc, c);
     set_vgrids(prm, wc, c);
     const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, nullptr};
-    const float gain = compute_gain(prm, wc, cx, c);
+    const float gain = compute_gain(prm, wc, cx, c, s_gain);
     if (wc.lane == 0 && gain < 0.0f) kill[blockIdx.x] = 1;
 }
 // Filter::filterExact, filter.cpp:148-263
