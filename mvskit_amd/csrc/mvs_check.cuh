@@ -14,17 +14,20 @@ namespace mvsdev {
 // LDS of the neighbour search: a hash set / sorted id list of HCAP ints and 3 floats per neighbour kept for filterQuad.
 // Optim::check (inside the sweep) uses the small configuration; Filter::filterNeighbor, which sees the untrimmed lists
 // of every patch, the large one.
-#define MVS_HASH_CAP 1024
-#ifndef MVS_ROW_CAP
-#define MVS_ROW_CAP 448   // 4 KB hash set + 3 x 448 rows + the 768 B of static LDS = 10 KB: 16 waves per CU
-#endif
-#define MVS_CHECK_LDS_FLOATS (MVS_HASH_CAP + 3 * MVS_ROW_CAP)
-#ifndef MVS_FILTER_HASH_CAP
-#define MVS_FILTER_HASH_CAP 1024   // first launch over all patches: 10 KB of LDS per wave (4 waves per SIMD)
-#define MVS_FILTER_ROW_CAP 448      // the same limits as Optim::check: the oracle picks the table size by one rule
-#endif
-#define MVS_FILTER2_HASH_CAP 16384 // second launch over the patches the first could not hold: 112 KB
+// One LDS region of MVS_SET_LDS_FLOATS dwords serves the whole neighbour search: first the id set (HCAP slots), then --
+// the accepted ids compacted to its front -- the 3 floats per neighbour filterQuad keeps, stored behind the ids.
+// 2048 slots (at most 7/8 visited) and 576 neighbours fit 9472 B, which with the 768 B of static LDS is 10 KB per wave:
+// 16 waves per CU.  The oracle picks the table size by the same rule (engine_neighbor_order).
+#define MVS_HASH_CAP 2048
+#define MVS_ROW_CAP 576
+#define MVS_SET_LDS_FLOATS(HCAP, RCAP) ((HCAP) > 4 * (RCAP) ? (HCAP) : 4 * (RCAP))
+#define MVS_CHECK_LDS_FLOATS 2368
+static_assert(MVS_SET_LDS_FLOATS(MVS_HASH_CAP, MVS_ROW_CAP) <= MVS_CHECK_LDS_FLOATS, "neighbour search LDS");
+#define MVS_FILTER_HASH_CAP MVS_HASH_CAP   // Filter::filterNeighbor, first launch over all patches: the same limits
+#define MVS_FILTER_ROW_CAP MVS_ROW_CAP
+#define MVS_FILTER2_HASH_CAP 16384         // second launch over the patches the first could not hold: 64 KB
 #define MVS_FILTER2_ROW_CAP 4096
+DEV int rows_offset(int n) { return (n + 63) & ~63; }  // the rows start behind the ids, on a 256-byte boundary
 
 struct CheckCtx {
     const DPatch* staging;  // records created by this pass (ids >= MVS_NEWBASE)
@@ -265,6 +268,9 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     }
     __syncthreads();
     CK_ADD(10)
+#ifdef MVS_STAGE_TIMING
+    if (cx.st && wc.lane == 0) { atomicMax(cx.st + 12, (unsigned long long)visited); atomicMax(cx.st + 13, (unsigned long long)count); }
+#endif
     if (visited > HCAP - HCAP / 8) return -1;  // beyond 7/8 full the oracle's table-size rule picks the next size
     return count;
 }
@@ -413,7 +419,7 @@ DEV int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, C
     if (6 < n) {
         if (n > MVS_ROW_CAP) { n = MVS_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }
         CK_BEGIN()
-        const int fq = filter_quad(prm, wc, cx, c, table, n, lds + MVS_HASH_CAP);
+        const int fq = filter_quad(prm, wc, cx, c, table, n, lds + rows_offset(n));
         CK_ADD(11)
         if (fq) { c.nimg = 0; return 1; }
     }

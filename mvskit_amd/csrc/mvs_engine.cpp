@@ -630,11 +630,11 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hc.stage[k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
         static const char* nm2[4] = {"gain", "search", "sort", "quad"};
         for (int k = 0; k < 4; ++k) fprintf(stderr, " %s %.1f%%", nm2[k], 100.0 * (double)hc.stage[8 + k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
-        fprintf(stderr, "  (wave cycles %.3e)\n", (double)hc.stage[0]);
+        fprintf(stderr, "  (wave cycles %.3e; max visited %llu, max neighbours %llu)\n", (double)hc.stage[0], hc.stage[12], hc.stage[13]);
     }
 #endif
     if (herr & 3) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
-    if (herr & 4) { g_err = "mvs_engine_pass: Optim::check met more than 512 neighbours of one patch (engine limit)"; return MVS_ERR_CAPACITY; }
+    if (herr & 4) { g_err = "mvs_engine_pass: Optim::check met more than 1792 patches around one patch, or more than 576 neighbours (engine limit)"; return MVS_ERR_CAPACITY; }
     return MVS_OK;
 }
 
@@ -764,7 +764,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     e->timing.index_ms = ms;  // whole Filter::run
     e->index_valid = false;
     if (removed4) for (int k = 0; k < 4; ++k) removed4[k] = rem[k];
-    if (herr & 4) { g_err = "mvs_engine_filter: more than 4096 neighbours of one patch (engine limit)"; return MVS_ERR_CAPACITY; }
+    if (herr & 4) { g_err = "mvs_engine_filter: more than 14336 patches around one patch, or more than 4096 neighbours (engine limit)"; return MVS_ERR_CAPACITY; }
     return MVS_OK;
 }
 

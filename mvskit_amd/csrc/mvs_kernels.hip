@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* ki
         }
         return;
     }
-    const bool reject = n < 6 || filter_quad(prm, wc, cx, c, table, n, s_lds + HCAP) != 0;
+    const bool reject = n < 6 || filter_quad(prm, wc, cx, c, table, n, s_lds + rows_offset(n)) != 0;
     if (wc.lane == 0 && reject) kill[id] = 1;
 }
 // Filter::filterSmallGroups, filter.cpp:432-578, as connected components of the symmetrised relation: lock-free
@@ -856,12 +856,12 @@ void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* ev
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, hipStream_t st) {
     if (prm.pool_n <= 0) return;
     hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP>), dim3((unsigned)prm.pool_n), dim3(64),
-                       (size_t)(MVS_FILTER_HASH_CAP + 3 * MVS_FILTER_ROW_CAP) * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow);
+                       (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow);
 }
 void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* overflow, hipStream_t st) {
     if (ntodo <= 0) return;
     hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP>), dim3((unsigned)ntodo), dim3(64),
-                       (size_t)(MVS_FILTER2_HASH_CAP + 3 * MVS_FILTER2_ROW_CAP) * sizeof(float), st, prm, kill, todo, ntodo, (int32_t*)nullptr, (int32_t*)nullptr, overflow);
+                       (size_t)MVS_SET_LDS_FLOATS(MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP) * sizeof(float), st, prm, kill, todo, ntodo, (int32_t*)nullptr, (int32_t*)nullptr, overflow);
 }
 void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st) {
     if (prm.pool_n <= 0) return;

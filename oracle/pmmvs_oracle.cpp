@@ -993,12 +993,12 @@ float compute_radius(const Scene& s, const Patch& p) {
  * the neighbours through a hash set of every id it meets in the scanned cell lists (`visited`), an ordered
  * linear-probing table (each key sits behind larger keys only), whose layout does not depend on the order of the
  * insertions: it is the layout of inserting the keys in descending order with plain linear probing.  The accepted ids
- * are taken in slot order.  Table size: 1024 slots while at most 7/8 of them are visited and at most 448 ids are
+ * are taken in slot order.  Table size: 2048 slots while at most 7/8 of them are visited and at most 576 ids are
  * accepted (mvs_check.cuh: MVS_HASH_CAP, MVS_ROW_CAP), else 16384 (Filter::filterNeighbor's second launch). */
 void engine_neighbor_order(std::vector<int> visited, std::vector<int>& nb /* sorted unique in, slot order out */) {
     std::sort(visited.begin(), visited.end());
     visited.erase(std::unique(visited.begin(), visited.end()), visited.end());
-    size_t cap = (visited.size() <= 896 && nb.size() <= 448) ? 1024 : 16384;
+    size_t cap = (visited.size() <= 1792 && nb.size() <= 576) ? 2048 : 16384;
     while (visited.size() * 8 > cap * 7) cap *= 2; /* beyond the engine's limits (it reports an error there) */
     std::vector<int> table(cap, -1);
     for (size_t k = visited.size(); k-- > 0;) {
