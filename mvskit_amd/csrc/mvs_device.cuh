@@ -1059,7 +1059,9 @@ DEV WaveCtx make_wave_ctx(const DParams& prm) {
 // Propagate::generatePatch, propagate.cpp:220-237.  `src` is in registers (view lanes hold m_images).
 // as_view >= 0 (view propagation): the patch is re-anchored on the ray of view `as_view` and Optim::swapImage
 // (optim.cpp:385-395) makes that view the reference.
-STAGE bool generate_patch(const DParams& prm, WaveCtx& wc, int* scratch, const Cand& src, F3 icoord, Cand& out, int as_view = -1) {
+// need_ncc = false (engine schedule, destination cell not full): the initial score is only ever read by the
+// replace-worst pre-filter (propagate.cpp:170); refinePatch overwrites it, so it is not computed when nothing reads it.
+STAGE bool generate_patch(const DParams& prm, WaveCtx& wc, int* scratch, const Cand& src, F3 icoord, Cand& out, int as_view = -1, bool need_ncc = true) {
     int simg = src.img;
     if (as_view >= 0 && rli(src.img, 0) != as_view) {
         const unsigned long long hit = ballot(0 < wc.lane && wc.lane < src.nimg && src.img == as_view);
@@ -1092,7 +1094,7 @@ STAGE bool generate_patch(const DParams& prm, WaveCtx& wc, int* scratch, const C
     out.nimg = __popcll(m);
     out.img = scratch[wc.lane]; out.gx = scratch[64 + wc.lane]; out.gy = scratch[128 + wc.lane];
     if (out.nimg == 0) return false;
-    out.ncc = compute_ncc(prm, wc, out.coord, out.normal, out.img, out.nimg);
+    if (need_ncc) out.ncc = compute_ncc(prm, wc, out.coord, out.normal, out.img, out.nimg);
     return true;
 }
 

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
                 {
                     Cand src;  // loaded per trial: its registers are free again during the refinement
                     load_cand(sp, wc, src);
-                    const bool gen_ok = generate_patch(prm, wc, s_scratch, src, ic, c, as_view);
+                    const bool gen_ok = generate_patch(prm, wc, s_scratch, src, ic, c, as_view, np >= prm.cap);
                     ST_ADD(1, st_t)
                     if (!gen_ok) continue;
                 }

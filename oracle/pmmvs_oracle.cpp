@@ -1355,7 +1355,9 @@ int post_process(const Scene& s, Patch& p, const DestCtx* ctx, orc_counters* cnt
 /* as_image >= 0 (view propagation, trash/propagate_view_propagation_simiar_to_original.cpp:125-147): the patch is
  * re-anchored on the ray of view `as_image` instead of its reference view -- depth along that view's optical axis,
  * back-projection through that view -- and Optim::swapImage (optim.cpp:385-395) makes it the reference view. */
-bool generate_patch(const Scene& s, const Patch& src, const V3& icoord, Patch& out, orc_counters* cnt, int as_image = -1) {
+/* need_ncc = false (engine schedule, destination cell not full): the initial m_ncc is read by the replace-worst pre-filter
+ * only (propagate.cpp:170) and overwritten by refinePatch, so the engine does not compute it when nothing reads it. */
+bool generate_patch(const Scene& s, const Patch& src, const V3& icoord, Patch& out, orc_counters* cnt, int as_image = -1, bool need_ncc = true) {
     out = Patch();
     int images[LISTCAP];
     for (int i = 0; i < src.nimg; ++i) images[i] = src.img[i];
@@ -1373,7 +1375,7 @@ bool generate_patch(const Scene& s, const Patch& src, const V3& icoord, Patch& o
     out.normal = src.normal;
     set_grids_images(s, out, images, src.nimg);
     if (out.nimg == 0) return false;
-    out.ncc = compute_ncc(s, out, cnt);
+    if (need_ncc) out.ncc = compute_ncc(s, out, cnt);
     return true;
 }
 
@@ -1611,7 +1613,7 @@ void propagate_patch_engine(const Scene& s, DestCtx& ctx, int src, int image, in
             const float a = rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], 0) * s.cfg.csize;
             const float b = rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], 1) * s.cfg.csize;
             const V3 nic{icoord.x + a, icoord.y + b, 1.0f};
-            if (!generate_patch(s, srcp, nic, cand, &cnt, as_image)) continue;
+            if (!generate_patch(s, srcp, nic, cand, &cnt, as_image, false)) continue;
             cnt.candidates++;
         } else {
             worst = ctx.list[s.cap - 1];
