@@ -37,7 +37,7 @@ struct CheckCtx {
 };
 #ifdef MVS_STAGE_TIMING
 #define CK_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
-#define CK_ADD(k) { const unsigned long long t1_ = CK_NOW(); if (cx.st && wc.lane == 0) atomicAdd(cx.st + (k), t1_ - ck_t); ck_t = t1_; }
+#define CK_ADD(k) { const unsigned long long t1_ = CK_NOW(); if (cx.st) cx.st[k] += t1_ - ck_t; ck_t = t1_; }
 #define CK_BEGIN() unsigned long long ck_t = CK_NOW();
 #else
 #define CK_ADD(k)
@@ -269,7 +269,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     __syncthreads();
     CK_ADD(10)
 #ifdef MVS_STAGE_TIMING
-    if (cx.st && wc.lane == 0) { atomicMax(cx.st + 12, (unsigned long long)visited); atomicMax(cx.st + 13, (unsigned long long)count); }
+    if (cx.st) { cx.st[12] = cx.st[12] > (unsigned long long)visited ? cx.st[12] : (unsigned long long)visited; cx.st[13] = cx.st[13] > (unsigned long long)count ? cx.st[13] : (unsigned long long)count; }
 #endif
     if (visited > HCAP - HCAP / 8) return -1;  // beyond 7/8 full the oracle's table-size rule picks the next size
     return count;

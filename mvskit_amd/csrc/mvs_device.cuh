@@ -334,7 +334,18 @@ struct WaveCtx {
     float fx, fy;       // this lane's sample column / row
     float fm;           // 1 on sample lanes, 0 elsewhere
     unsigned evals, view_evals;
+#ifdef MVS_STAGE_TIMING
+    unsigned long long st_acc[8];  // diagnostic build: phase times, kept in registers and flushed once by the kernel
+    unsigned long long st_t;
+#endif
 };
+#ifdef MVS_STAGE_TIMING
+#define WC_T0(wc) { (wc).st_t = (unsigned long long)__builtin_amdgcn_s_memtime(); }
+#define WC_ADD(wc, k) { const unsigned long long t1_ = (unsigned long long)__builtin_amdgcn_s_memtime(); (wc).st_acc[k] += t1_ - (wc).st_t; (wc).st_t = t1_; }
+#else
+#define WC_T0(wc)
+#define WC_ADD(wc, k)
+#endif
 
 // Tail of Optim::getTex (sampling, optim.cpp:835-842 -> Image::getColor bilinear, image.cpp:447-472) and
 // Optim::normalize (optim.cpp:917-940) for frame lane e, split in two so that the loads of the next views are in
@@ -872,11 +883,13 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     if (c.nimg == 0) return;
     const int n = c.nimg;
     const int ref = rli(c.img, 0);
+    WC_T0(wc)
     F4 px, py;
     get_paxes(prm, prm.views + ref, c.coord, c.normal, px, py);
     wc.evals++;
     const Frame f = make_frame(prm, c.coord, px, py, c.normal, c.img, wc.lane < n);
     unsigned okmask = 0;
+    WC_ADD(wc, 1)
     __syncthreads();
     // centred textures to LDS (three views in flight per step), their ssd to view lanes
     float ssd_l = 1.0f;
@@ -912,6 +925,7 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
         }
     }
     const float inv_l = inv_msd(prm, ssd_l);
+    WC_ADD(wc, 2)
     __syncthreads();
     // one lane per pair (a, b), a < b < n; up to 120 pairs = 2 rounds of 64 lanes
     const int npairs = n * (n - 1) / 2;
@@ -932,6 +946,7 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
         if (!(act && ((okmask >> a) & 1u) && ((okmask >> b) & 1u))) val = 2.0f;
         if (r == 0) val0 = val; else val1 = val;
     }
+    WC_ADD(wc, 3)
     // view lane i: sum over j of inccs[i][j], j ascending (std::accumulate, optim.cpp:368)
     float acc = 0.0f;
     for (int j = 0; j < n; ++j) {
@@ -946,6 +961,7 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     const bool cand = wc.lane < n && acc < big;
     const float m = wave_min(cand ? acc : __int_as_float(0x7f800000));
     const unsigned long long eq = ballot(cand && acc == m);
+    WC_ADD(wc, 4)
     if (!eq) return;
     const int refindex = __ffsll((long long)eq) - 1;
     const int vref = rli(c.img, refindex), v0 = rli(c.img, 0);
@@ -1053,6 +1069,10 @@ DEV WaveCtx make_wave_ctx(const DParams& prm) {
     wc.fx = (float)(wc.lane % prm.wsize);
     wc.fy = (float)(wc.lane / prm.wsize);
     wc.evals = 0; wc.view_evals = 0;
+#ifdef MVS_STAGE_TIMING
+    for (int k = 0; k < 8; ++k) wc.st_acc[k] = 0;
+    wc.st_t = 0;
+#endif
     return wc;
 }
 

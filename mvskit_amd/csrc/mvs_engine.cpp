@@ -728,7 +728,21 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     if (int r = apply_kills(e, &rem[0])) return r;
     if (int r = filter_rebuild(e, 1)) return r;
     HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
-    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, st);          // filterExact
+#ifdef MVS_STAGE_TIMING
+    HIPCHK(hipMemsetAsync(e->counters.p, 0, sizeof(DCounters), st));
+    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, e->counters.p->stage, st);
+    {
+        DCounters hc;
+        HIPCHK(hipMemcpyAsync(&hc, e->counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        static const char* nm[7] = {"wave", "frames", "sampling", "pair sums", "choice", "load", "visibility"};
+        fprintf(stderr, "[filterExact cycles]");
+        for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hc.stage[k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
+        fprintf(stderr, " (wave cycles %.3e)\n", (double)hc.stage[0]);
+    }
+#else
+    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, nullptr, st);          // filterExact
+#endif
     if (int r = apply_kills(e, &rem[1])) return r;
     if (int r = filter_rebuild(e, 1)) return r;
     {                                                                              // filterNeighbor(1)

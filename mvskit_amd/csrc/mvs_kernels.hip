@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
 #ifdef MVS_STAGE_TIMING
 #define ST_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
 #define ST_ADD(k, t0) { const unsigned long long t1_ = ST_NOW(); st_acc[k] += t1_ - (t0); (t0) = t1_; }
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long st_begin = ST_NOW();
     unsigned long long st_t = st_begin;
 #else
@@ -399,7 +399,11 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
                     __syncthreads();
                     if (wc.lane < MVS_CAPMAX) s_scratch[wc.lane] = L_id;  // publish the live list of this cell
                     __syncthreads();
-                    const CheckCtx cx{a.staging, v, cell, L_n, s_scratch, a.counters->stage};
+                    #ifdef MVS_STAGE_TIMING
+                    const CheckCtx cx{a.staging, v, cell, L_n, s_scratch, st_acc};
+#else
+                    const CheckCtx cx{a.staging, v, cell, L_n, s_scratch, nullptr};
+#endif
                     const int chk_r = check_patch(prm, wc, cx, c, s_texs, a.error_flag);
                     ST_ADD(5, st_t)
                     if (chk_r) { ++n_f1; continue; }
@@ -452,7 +456,8 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
         if (wc.view_evals) atomicAdd(&C->view_evals, (unsigned long long)wc.view_evals);
 #ifdef MVS_STAGE_TIMING
         st_acc[0] = ST_NOW() - st_begin;
-        for (int k = 0; k < 8; ++k) if (st_acc[k]) atomicAdd(&C->stage[k], st_acc[k]);
+        for (int k = 0; k < 12; ++k) if (st_acc[k]) atomicAdd(&C->stage[k], st_acc[k]);
+        atomicMax(&C->stage[12], st_acc[12]); atomicMax(&C->stage[13], st_acc[13]);
 #endif
     }
 }
@@ -565,15 +570,20 @@ __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kil
     if (wc.lane == 0 && gain < 0.0f) kill[blockIdx.x] = 1;
 }
 // Filter::filterExact, filter.cpp:148-263
-__global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill, unsigned long long* evals) {
+__global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage) {
     __shared__ int s_scratch[192];
     extern __shared__ float s_texs[];
     DPatch* p = prm.pool + blockIdx.x;
     if (!(p->flags & 1)) return;
     WaveCtx wc = make_wave_ctx(prm);
+#ifdef MVS_STAGE_TIMING
+    const unsigned long long fe_begin = (unsigned long long)__builtin_amdgcn_s_memtime();
+    WC_T0(wc)
+#endif
     Cand c;
     load_cand(p, wc, c);
     set_grids(prm, wc, c);
+    WC_ADD(wc, 5)
     // view lane i: does view m_images[i] survive?  (filterExactSub: own cell, then the 4 neighbouring cells)
     bool safe = false;
     if (wc.lane < c.nimg) {
@@ -587,6 +597,7 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
                    (y < h - 1 && is_visible(prm, c, image, x, y + 1, thr));
         }
     }
+    WC_ADD(wc, 6)
     // the survivors in ascending view order (the image-major loop of filterExactSub)
     __syncthreads();
     if (wc.lane < MVS_MAXVIEWS) s_scratch[wc.lane] = 0;
@@ -609,6 +620,12 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
         if (wc.lane == 0) kill[blockIdx.x] = 1;
     }
     if (wc.lane == 0) { atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
+#ifdef MVS_STAGE_TIMING
+    if (stage && wc.lane == 0) {
+        atomicAdd(stage, (unsigned long long)__builtin_amdgcn_s_memtime() - fe_begin);
+        for (int k = 1; k < 8; ++k) atomicAdd(stage + k, wc.st_acc[k]);
+    }
+#endif
 }
 // Filter::filterNeighbor(1), filter.cpp:265-327: fewer than 6 neighbours, or a bad quadric fit.
 // First launch (todo == nullptr): every patch, with a hash set / row buffer that fits 2 waves per SIMD; a patch that
@@ -850,8 +867,8 @@ void mvsk_filter_vimages(const DParams& prm, int additive, hipStream_t st) {
 void mvsk_filter_outside(const DParams& prm, uint8_t* kill, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_outside, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, kill);
 }
-void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)prm.pool_n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals);
+void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)prm.pool_n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals, stage);
 }
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, hipStream_t st) {
     if (prm.pool_n <= 0) return;
