@@ -285,25 +285,37 @@ DEV int level_diff(const DParams& prm, float ratio) {
     return max(-prm.level, min(2, ld));
 }
 DEV float pow2_level(int ld) { return __int_as_float((127 + ld) << 23); }  // Optim::myPow2, exact powers of two
+// Camera::project on a projection matrix held in registers, without a branch (same values as project())
+DEV F3 project_regs(const float (&P)[12], F4 X) {
+    const float r0 = fma_(P[3], X.w, fma_(P[2], X.z, fma_(P[1], X.y, P[0] * X.x)));
+    const float r1 = fma_(P[7], X.w, fma_(P[6], X.z, fma_(P[5], X.y, P[4] * X.x)));
+    const float r2 = fma_(P[11], X.w, fma_(P[10], X.z, fma_(P[9], X.y, P[8] * X.x)));
+    const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
+    const float inv = 1.0f / r2;
+    F3 ic{fmaxf(lo, fminf(hi, r0 * inv)), fmaxf(lo, fminf(hi, r1 * inv)), 1.0f};
+    if (r2 <= 0.0f) ic = {-65535.0f, -65535.0f, -1.0f};
+    return ic;
+}
+// Straight-line: every load of the view's constants is issued at the top (one wait instead of one per early exit --
+// a lane that leaves early saves nothing while its neighbours go on), the gates only select the result.
 DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, bool active) {
-    Frame f{0, 0, 0, 0, 0, 0, 4, 0, 0, 0};
-    if (!active) return f;
-    const DView* vw = prm.views + v;
-    {
-        const unsigned long long a = (unsigned long long)vw->img[prm.level];
-        f.img_lo = (unsigned)(a & 0xffffffffull); f.img_hi = (unsigned)(a >> 32);
-        f.w = vw->W[prm.level];
-    }
-    const F4 ray = nrm4(sub4(ld4(vw->center), coord));
+    const DView* vw = prm.views + (active ? v : 0);
+    const F4 ctr = ld4(vw->center);
+    float P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = vw->P[prm.level][k];
+    const int W0 = vw->W[0], H0 = vw->H[0];
+    const unsigned long long base_level = (unsigned long long)vw->img[prm.level];
+    const F4 ray = nrm4(sub4(ctr, coord));
     const float weight = fmaxf(0.0f, dot4(ray, pz));
-    if (weight < prm.cosAngle1) return f;
-    F3 center = project(vw, coord, prm.level);
-    F3 dx = sub3(project(vw, add4(coord, px), prm.level), center);
-    F3 dy = sub3(project(vw, add4(coord, py), prm.level), center);
+    F3 center = project_regs(P, coord);
+    F3 dx = sub3(project_regs(P, add4(coord, px)), center);
+    F3 dy = sub3(project_regs(P, add4(coord, py)), center);
     const float ratio = (norm3(dx) + norm3(dy)) / 2.0f;
     const int ld = level_diff(prm, ratio);
     const float iscale = pow2_level(-ld);  // exact reciprocal of a power of two
     const int newLevel = prm.level + ld;
+    const unsigned long long base_new = (unsigned long long)vw->img[newLevel];  // the one load that depends on the arithmetic
     center = scl3(center, iscale);
     dx = scl3(dx, iscale);
     dy = scl3(dy, iscale);
@@ -316,11 +328,15 @@ DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, b
     const float minx = fminf(tlx, fminf(trx, fminf(blx, brx))), maxx = fmaxf(tlx, fmaxf(trx, fmaxf(blx, brx)));
     const float miny = fminf(tly, fminf(try_, fminf(bly, bry))), maxy = fmaxf(tly, fmaxf(try_, fmaxf(bly, bry)));
     const int margin2 = 2;
-    const int W = vw->W[newLevel];
-    if (minx < margin2 || W - 1 - margin2 <= maxx || miny < margin2 || vw->H[newLevel] - 1 - margin2 <= maxy) return f;
-    f.tlx = tlx; f.tly = tly; f.dxx = dx.x; f.dxy = dx.y; f.dyx = dy.x; f.dyy = dy.y;
-    f.w = W; f.ok = 1;
-    const unsigned long long a = (unsigned long long)vw->img[newLevel];
+    const int W = W0 >> newLevel, H = H0 >> newLevel;  // the pyramid halves (rounding down) at every level
+    const bool inside = !(minx < margin2 || W - 1 - margin2 <= maxx || miny < margin2 || H - 1 - margin2 <= maxy);
+    const bool ok = active && !(weight < prm.cosAngle1) && inside;
+    Frame f;
+    f.tlx = ok ? tlx : 0.0f; f.tly = ok ? tly : 0.0f;
+    f.dxx = ok ? dx.x : 0.0f; f.dxy = ok ? dx.y : 0.0f; f.dyx = ok ? dy.x : 0.0f; f.dyy = ok ? dy.y : 0.0f;
+    f.w = ok ? W : (W0 >> prm.level);
+    f.ok = ok ? 1 : 0;
+    const unsigned long long a = ok ? base_new : base_level;
     f.img_lo = (unsigned)(a & 0xffffffffull); f.img_hi = (unsigned)(a >> 32);
     return f;
 }
