@@ -224,6 +224,21 @@ DEV F3 project(const DView* vw, F4 X, int level) {
     ic.y = fmaxf(lo, fminf(hi, ic.y));
     return ic;
 }
+// Camera::project on a projection matrix held in registers, without a branch (same values as project())
+DEV F3 project_regs(const float (&P)[12], F4 X) {
+    const float r0 = fma_(P[3], X.w, fma_(P[2], X.z, fma_(P[1], X.y, P[0] * X.x)));
+    const float r1 = fma_(P[7], X.w, fma_(P[6], X.z, fma_(P[5], X.y, P[4] * X.x)));
+    const float r2 = fma_(P[11], X.w, fma_(P[10], X.z, fma_(P[9], X.y, P[8] * X.x)));
+    const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
+    const float inv = 1.0f / r2;
+    F3 ic{fmaxf(lo, fminf(hi, r0 * inv)), fmaxf(lo, fminf(hi, r1 * inv)), 1.0f};
+    if (r2 <= 0.0f) ic = {-65535.0f, -65535.0f, -1.0f};
+    return ic;
+}
+DEV void load_P(const DView* vw, int level, float (&P)[12]) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = vw->P[level][k];
+}
 // Camera::unproject at m_level, camera.cpp:329-337
 DEV F4 unproject(const DView* vw, F3 ic, int level) {
     const float* P = vw->P[level];
@@ -241,22 +256,30 @@ DEV float get_unit(const DParams& prm, const DView* vw, F4 coord) {
 }
 // PatchManager::setGrids cell rule, patch_manager.cpp:241-250
 DEV void cell_of(const DParams& prm, const DView* vw, F4 coord, int& ix, int& iy) {
-    const F3 ic = project(vw, coord, prm.level);
+    float P[12];
+    load_P(vw, prm.level, P);
+    const F3 ic = project_regs(P, coord);
     ix = ((int)floorf(ic.x + 0.5f)) / prm.csize;
     iy = ((int)floorf(ic.y + 0.5f)) / prm.csize;
 }
-// Optim::getPAxes, optim.cpp:67-84
+// Optim::getPAxes, optim.cpp:67-84 (the view's constants are loaded once, up front)
 DEV void get_paxes(const DParams& prm, const DView* vw, F4 coord, F4 normal, F4& px, F4& py) {
-    const float pscale = get_unit(prm, vw, coord);
+    const F4 ctr = ld4(vw->center);
+    const float ips = vw->ipscale;
+    const F3 xax = ld3(vw->xaxis);
+    float P[12];
+    load_P(vw, prm.level, P);
+    float pscale = 1.0f;  // get_unit
+    if (ips != 0.0f) pscale = (2.0f * norm4(sub4(coord, ctr)) * (float)(1 << prm.level)) / ips;
     F3 n3{normal.x, normal.y, normal.z};
-    F3 y3 = cross3(n3, ld3(vw->xaxis));
+    F3 y3 = cross3(n3, xax);
     y3 = nrm3(y3);
     F3 x3 = cross3(y3, n3);
     px = {x3.x * pscale, x3.y * pscale, x3.z * pscale, 0.0f};
     py = {y3.x * pscale, y3.y * pscale, y3.z * pscale, 0.0f};
-    const F3 c0 = project(vw, coord, prm.level);
-    const float xdis = norm3(sub3(project(vw, add4(coord, px), prm.level), c0));
-    const float ydis = norm3(sub3(project(vw, add4(coord, py), prm.level), c0));
+    const F3 c0 = project_regs(P, coord);
+    const float xdis = norm3(sub3(project_regs(P, add4(coord, px)), c0));
+    const float ydis = norm3(sub3(project_regs(P, add4(coord, py)), c0));
     px = scl4(px, 1.0f / xdis);
     py = scl4(py, 1.0f / ydis);
 }
@@ -285,17 +308,6 @@ DEV int level_diff(const DParams& prm, float ratio) {
     return max(-prm.level, min(2, ld));
 }
 DEV float pow2_level(int ld) { return __int_as_float((127 + ld) << 23); }  // Optim::myPow2, exact powers of two
-// Camera::project on a projection matrix held in registers, without a branch (same values as project())
-DEV F3 project_regs(const float (&P)[12], F4 X) {
-    const float r0 = fma_(P[3], X.w, fma_(P[2], X.z, fma_(P[1], X.y, P[0] * X.x)));
-    const float r1 = fma_(P[7], X.w, fma_(P[6], X.z, fma_(P[5], X.y, P[4] * X.x)));
-    const float r2 = fma_(P[11], X.w, fma_(P[10], X.z, fma_(P[9], X.y, P[8] * X.x)));
-    const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
-    const float inv = 1.0f / r2;
-    F3 ic{fmaxf(lo, fminf(hi, r0 * inv)), fmaxf(lo, fminf(hi, r1 * inv)), 1.0f};
-    if (r2 <= 0.0f) ic = {-65535.0f, -65535.0f, -1.0f};
-    return ic;
-}
 // Straight-line: every load of the view's constants is issued at the top (one wait instead of one per early exit --
 // a lane that leaves early saves nothing while its neighbours go on), the gates only select the result.
 DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, bool active) {
@@ -625,11 +637,13 @@ DEV void add_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c
     bool q = false;
     if (wc.lane < prm.nviews && wc.lane != ref && !visib) {
         const DView* vw = prm.views + wc.lane;
-        const F3 ic = project(vw, c.coord, prm.level);
-        if (!(ic.x < 0.0f || vw->W[prm.level] - 1 <= ic.x || ic.y < 0.0f || vw->H[prm.level] - 1 <= ic.y)) {
-            const F4 ray = nrm4(sub4(ld4(vw->center), c.coord));
-            q = prm.cosAngle0 <= dot4(ray, c.normal);
-        }
+        float P[12];
+        load_P(vw, prm.level, P);
+        const int W = vw->W[prm.level], H = vw->H[prm.level];
+        const F4 ctr = ld4(vw->center);
+        const F3 ic = project_regs(P, c.coord);
+        const F4 ray = nrm4(sub4(ctr, c.coord));
+        q = !(ic.x < 0.0f || W - 1 <= ic.x || ic.y < 0.0f || H - 1 <= ic.y) && prm.cosAngle0 <= dot4(ray, c.normal);
     }
     const unsigned long long m = ballot(q);
     const int pos = c.nimg + __popcll(m & ((1ull << wc.lane) - 1ull));
