@@ -558,12 +558,17 @@ struct Cand {
 // Optim::computeUnits + computeWeights, optim.cpp:109-132, 942-948: returns the view-lane weight array
 DEV float compute_weights(const DParams& prm, const WaveCtx& wc, F4 coord, F4 normal, int img, int n) {
     float unit = 1.0f;
-    if (wc.lane < n) {
-        const DView* vw = prm.views + img;
-        unit = get_unit(prm, vw, coord);
-        const F4 ray = nrm4(sub4(ld4(vw->center), coord));
+    {
+        const DView* vw = prm.views + (wc.lane < n ? img : 0);
+        const F4 ctr = ld4(vw->center);
+        const float ips = vw->ipscale;
+        const F4 dc = sub4(coord, ctr);
+        float u = 1.0f;  // get_unit
+        if (ips != 0.0f) u = (2.0f * norm4(dc) * (float)(1 << prm.level)) / ips;
+        const F4 ray = nrm4(sub4(ctr, coord));
         const float d = dot4(ray, normal);
-        if (0.0f < d) unit /= d; else unit = (float)(INT_MAX / 2);
+        u = (0.0f < d) ? u / d : (float)(INT_MAX / 2);
+        if (wc.lane < n) unit = u;
     }
     const float w0 = rlf(unit, 0);
     float w = fminf(1.0f, w0 / unit);
@@ -667,12 +672,18 @@ DEV void sort_images(const DParams& prm, const WaveCtx& wc, Cand& c) {
     F4 ray{0, 0, 0, 0};
     float unit = 0.0f;
     bool valid = false;
-    if (wc.lane < c.nimg) {  // computeUnits(patch, indexes, units, rays), optim.cpp:86-107
-        const DView* vw = prm.views + c.img;
-        ray = nrm4(sub4(ld4(vw->center), c.coord));
-        const float d = dot4(ray, c.normal);
-        valid = !(d <= 0.0f);
-        if (valid) unit = get_unit(prm, vw, c.coord) / d;
+    {  // computeUnits(patch, indexes, units, rays), optim.cpp:86-107
+        const bool in = wc.lane < c.nimg;
+        const DView* vw = prm.views + (in ? c.img : 0);
+        const F4 ctr = ld4(vw->center);
+        const float ips = vw->ipscale;
+        const F4 r = nrm4(sub4(ctr, c.coord));
+        const float d = dot4(r, c.normal);
+        float u = 1.0f;  // get_unit
+        if (ips != 0.0f) u = (2.0f * norm4(sub4(c.coord, ctr)) * (float)(1 << prm.level)) / ips;
+        valid = in && !(d <= 0.0f);
+        if (in) ray = r;
+        if (valid) unit = u / d;
     }
     const unsigned long long vm = ballot(valid);
     const int n0 = __popcll(vm);
@@ -710,9 +721,12 @@ DEV void set_scales(const DParams& prm, const WaveCtx& wc, Cand& c) {
     const F4 ray = nrm4(sub4(c.coord, ld4(rv->center)));
     const int num = min(prm.tau, c.nimg);
     float dn = 0.0f;
-    if (wc.lane >= 1 && wc.lane < num) {
-        const DView* vw = prm.views + c.img;
-        dn = norm3(sub3(project(vw, c.coord, prm.level), project(vw, sub4(c.coord, mul4(ray, unit2)), prm.level)));
+    {
+        const bool in = wc.lane >= 1 && wc.lane < num;
+        float P[12];
+        load_P(prm.views + (in ? c.img : 0), prm.level, P);
+        const float d = norm3(sub3(project_regs(P, c.coord), project_regs(P, sub4(c.coord, mul4(ray, unit2)))));
+        if (in) dn = d;
     }
     float ds = c.dscale;
     for (int i = 1; i < num; ++i) ds += rlf(dn, i);
