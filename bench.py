@@ -146,7 +146,7 @@ def main():
         sc, seeds = load_scene(args, rank)
 
     e = eng.Engine(args.views, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=1, refine_steps=args.refine_steps,
-                   view_begin=rank, view_stride=world, device=local_rank)
+                   shard_index=rank, shard_count=world, device=local_rank)
     if rank == 0:
         log(f"scene ready: {sc.nviews} views {sc.W}x{sc.H}, {seeds.shape[0]} seeds")
     e.set_scene(sc)
@@ -216,7 +216,7 @@ def main():
                                    f"minImageNum 3, 1 seed per {args.seed_stride}x{args.seed_stride} cells per view, {args.steps} iterations after {args.warmup} warm-up",
                        "views": args.views, "width": args.width, "height": args.height, "csize": 2, "wsize": 7,
                        "refine_evals": 1 + 3 * args.refine_steps, "check_depth2": True, "filter_run": bool(args.filter),
-                       "parallelism": "single GPU" if world == 1 else f"views sharded over {world} GPUs, RCCL all-gather of patch records per colour pass"},
+                       "parallelism": "single GPU" if world == 1 else f"the (view, cell) sequence sharded in {world} contiguous ranges over {world} GPUs, RCCL all-gather of patch records per colour pass"},
             "patches": patches,
             "view_evals": view_evals,
             "pool_alive": n_alive,

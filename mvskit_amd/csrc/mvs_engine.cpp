@@ -345,6 +345,7 @@ void mvs_default_config(mvs_config* c) {  // Option::Option, option.cpp:19-33
 
 int mvs_engine_create(const mvs_config* cfg, mvs_engine** out) {
     if (!cfg || !out) { g_err = "mvs_engine_create: null argument"; return MVS_ERR_ARG; }
+    if (cfg->shard_count > 1 && (cfg->shard_index < 0 || cfg->shard_index >= cfg->shard_count)) { g_err = "mvs_engine_create: bad shard_index"; return MVS_ERR_ARG; }
     if (cfg->nviews < 1 || cfg->nviews > MVS_MAXVIEWS || cfg->wsize < 1 || cfg->wsize > 8 || cfg->csize < 1 || cfg->level < 0 ||
         cfg->level > 4 || cfg->max_propag < 1 || cfg->max_propag > 16 || cfg->max_propag * cfg->csize * cfg->csize > MVS_CAPMAX ||
         cfg->view_stride < 1 || cfg->view_begin < 0 || cfg->minImageNum < 1) {
@@ -585,13 +586,20 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     memset(&a, 0, sizeof a);
     a.iter = iter; a.inc = (iter % 2 == 0) ? 1 : -1; a.colour = pass & 1;
     int64_t nj = 0;
-    for (int v = e->cfg.view_begin; v < e->cfg.nviews; v += e->cfg.view_stride) {
+    const bool ranged = e->cfg.shard_count > 1;  // shard by job range over all views, else by whole views
+    for (int v = ranged ? 0 : e->cfg.view_begin; v < e->cfg.nviews; v += ranged ? 1 : e->cfg.view_stride) {
         a.sweep_views[a.nsweep_views] = v;
         a.job_base[a.nsweep_views] = (int32_t)nj;
         ++a.nsweep_views;
         nj += (int64_t)((e->hviews[v].gw + 1) / 2) * e->hviews[v].gh;
     }
     a.njobs = nj;
+    a.job_lo = 0; a.job_hi = nj;
+    if (ranged) {
+        a.job_lo = nj * e->cfg.shard_index / e->cfg.shard_count;
+        a.job_hi = nj * (e->cfg.shard_index + 1) / e->cfg.shard_count;
+        HIPCHK(hipMemsetAsync(e->job_nstage.p, 0, (size_t)nj * sizeof(int32_t), st));  // jobs of other shards stage nothing
+    }
     a.staging = e->staging.p; a.staging_cap = e->staging.cap;
     a.stage_counter = e->misc.p;
     a.job_stage = e->job_stage.p; a.job_nstage = e->job_nstage.p;

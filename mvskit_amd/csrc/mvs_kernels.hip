@@ -298,12 +298,12 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
     // expensive regions.  (One contiguous band of cells per XCD left XCDs idle for a quarter of the launch: the bands
     // -- one and a half views each -- differ in work; measured 770 -> 603 ms per iteration.)
     const int64_t bi = blockIdx.x >> 3;
-    const int64_t job = (bi / MVS_XCD_CHUNK) * (8 * MVS_XCD_CHUNK) + (int64_t)(blockIdx.x & 7u) * MVS_XCD_CHUNK + (bi % MVS_XCD_CHUNK);
+    const int64_t job = a.job_lo + (bi / MVS_XCD_CHUNK) * (8 * MVS_XCD_CHUNK) + (int64_t)(blockIdx.x & 7u) * MVS_XCD_CHUNK + (bi % MVS_XCD_CHUNK);
 #else
-    const int64_t chunk = (a.njobs + 7) / 8;
-    const int64_t job = (int64_t)(blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    const int64_t chunk = (a.job_hi - a.job_lo + 7) / 8;
+    const int64_t job = a.job_lo + (int64_t)(blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
 #endif
-    if (job >= a.njobs) return;
+    if (job >= a.job_hi) return;
     int s = 0;
     while (s + 1 < a.nsweep_views && job >= a.job_base[s + 1]) ++s;
     const int v = a.sweep_views[s];
@@ -831,12 +831,13 @@ size_t mvsk_sweep_lds_bytes(const DParams& prm) {
     return texs > chk ? texs : chk;
 }
 void mvsk_sweep(const DParams& prm, const SweepArgs& a, hipStream_t st) {
-    if (a.njobs <= 0) return;
-    const int64_t chunk = (a.njobs + 7) / 8;
+    const int64_t nloc = a.job_hi - a.job_lo;
+    if (nloc <= 0) return;
+    const int64_t chunk = (nloc + 7) / 8;
     // development knob: MVS_SWEEP_LDS_PAD=<bytes> raises the block's LDS allocation, i.e. lowers the waves per SIMD
     static const size_t pad = getenv("MVS_SWEEP_LDS_PAD") ? (size_t)atol(getenv("MVS_SWEEP_LDS_PAD")) : 0;
 #if MVS_XCD_CHUNK > 0
-    const int64_t nblocks = (a.njobs + 8 * MVS_XCD_CHUNK - 1) / (8 * MVS_XCD_CHUNK) * (8 * MVS_XCD_CHUNK);
+    const int64_t nblocks = (nloc + 8 * MVS_XCD_CHUNK - 1) / (8 * MVS_XCD_CHUNK) * (8 * MVS_XCD_CHUNK);
 #else
     const int64_t nblocks = chunk * 8;
 #endif

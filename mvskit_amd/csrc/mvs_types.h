@@ -95,6 +95,7 @@ struct SweepArgs {
     int32_t job_base[MVS_MAXVIEWS];  // first job id of each swept view
     int32_t halfw_max, gh_max;
     int64_t njobs;
+    int64_t job_lo, job_hi;  // the jobs this launch runs: [job_lo, job_hi) of [0, njobs) (sharding by job range)
     DPatch* staging;
     int64_t staging_cap;
     unsigned long long* stage_counter;

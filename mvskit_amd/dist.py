@@ -22,16 +22,19 @@ def owner_of(view: int, world: int) -> int:
 
 
 def merge_in_view_order(per_rank_records, per_rank_view_counts, nviews, world):
-    """Concatenate each rank's export (its own views in ascending order) into global view order.
+    """Concatenate the ranks' exports into the global (view, cell, creation) order.  Every rank's export is already in
+    that order over the cells it swept; a view is either owned by one rank (sharding by whole views) or cut into
+    contiguous cell ranges held by consecutive ranks (sharding by job range), so within a view the ranks' pieces follow
+    each other in rank order.
     per_rank_records[r]: uint8 array/tensor [n_r, 128]; per_rank_view_counts[r]: int array [nviews]."""
     offsets = [0] * world
     parts = []
     for v in range(nviews):
-        r = owner_of(v, world)
-        c = int(per_rank_view_counts[r][v])
-        if c:
-            parts.append(per_rank_records[r][offsets[r]: offsets[r] + c])
-            offsets[r] += c
+        for r in range(world):
+            c = int(per_rank_view_counts[r][v])
+            if c:
+                parts.append(per_rank_records[r][offsets[r]: offsets[r] + c])
+                offsets[r] += c
     return parts
 
 

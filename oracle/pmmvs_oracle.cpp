@@ -1693,7 +1693,8 @@ void engine_pass(Scene& s, int iter, int pass) {
     s.staged_cells.clear();
     struct Job { int v, cell; };
     std::vector<Job> jobs;
-    const int vb = s.cfg.view_begin, vs = std::max(1, s.cfg.view_stride);
+    const bool ranged = s.cfg.shard_count > 1;
+    const int vb = ranged ? 0 : s.cfg.view_begin, vs = ranged ? 1 : std::max(1, s.cfg.view_stride);
     for (int v = vb; v < s.cfg.nviews; v += vs) {
         const View& vw = s.views[v];
         for (int cy = 0; cy < vw.gh; ++cy) for (int cx = 0; cx < vw.gw; ++cx) {
@@ -1709,6 +1710,11 @@ void engine_pass(Scene& s, int iter, int pass) {
             if (s.cfg.view_propagation) { const int sc = cy * vw.gw + cx; has = has || s.csr_start[v][sc + 1] > s.csr_start[v][sc]; }
             if (has) jobs.push_back({v, cy * vw.gw + cx});
         }
+    }
+    if (ranged) { /* this shard's contiguous range of the (view, cell) sequence */
+        const size_t lo = jobs.size() * (size_t)s.cfg.shard_index / (size_t)s.cfg.shard_count;
+        const size_t hi = jobs.size() * (size_t)(s.cfg.shard_index + 1) / (size_t)s.cfg.shard_count;
+        jobs = std::vector<Job>(jobs.begin() + lo, jobs.begin() + hi);
     }
     std::vector<DestCtx> out(jobs.size());
     const int nthreads = std::max(1, s.cfg.nthreads);

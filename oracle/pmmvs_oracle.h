@@ -66,6 +66,8 @@ typedef struct orc_config {
     int32_t view_stride;
     int32_t nthreads;     /* engine schedule only: OpenMP threads over destination cells */
     int32_t view_propagation; /* engine schedule only: the disabled branch of propagate.cpp:110-120 (see dest_cell_engine) */
+    int32_t shard_index;  /* engine schedule, shard_count > 1: sweep the shard_index-th of shard_count contiguous ranges */
+    int32_t shard_count;  /*   of the destination cells of all views (view_begin / view_stride ignored) */
 } orc_config;
 
 typedef struct orc_counters {

@@ -31,7 +31,7 @@ def test_record_layouts_match_header():
     assert engine.PATCH_DTYPE.itemsize == 128
     assert engine.PATCH_DTYPE.fields["images"][1] == 64 and engine.PATCH_DTYPE.fields["vimages"][1] == 96
     assert C.sizeof(engine.Counters) == 80
-    assert C.sizeof(engine.Config) == 88
+    assert C.sizeof(engine.Config) == 96
 
 
 def test_default_config_follows_option_defaults(lib):

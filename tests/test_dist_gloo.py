@@ -28,7 +28,7 @@ def _scene():
     return sc, seeds
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, ranged=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -40,8 +40,9 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc, seeds = _scene()
+    shard = dict(shard_index=rank, shard_count=world) if ranged else dict(view_begin=rank, view_stride=world)
     o = ob.Oracle(sc.nviews, level=0, minImageNum=2, enable_check=0, seed=5, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64,
-                  view_begin=rank, view_stride=world, nthreads=2)
+                  nthreads=2, **shard)
     o.set_scene(sc)
     o.add_patches(seeds)
     ex = mdist.HostExchange()
@@ -54,7 +55,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank(tmp_path):
+@pytest.mark.parametrize("world,ranged", [(2, False), (3, True)])
+def test_ranks_equal_one_rank(tmp_path, world, ranged):
+    """world 2 sharded by whole views; world 3 by contiguous ranges of the (view, cell) sequence (4 views do not divide
+    by 3: a view is split between two ranks)."""
     import oracle_binding as ob
 
     sc, seeds = _scene()
@@ -68,14 +72,13 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert patches > 500 and single.shape[0] > seeds.shape[0]
 
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    p0 = np.load(tmp_path / "pool_0.npy").view(ob.PATCH_DTYPE).reshape(-1)
-    p1 = np.load(tmp_path / "pool_1.npy").view(ob.PATCH_DTYPE).reshape(-1)
-    n = int(np.load(tmp_path / "patches_0.npy")[0] + np.load(tmp_path / "patches_1.npy")[0])
-    assert n == patches  # the two ranks together did exactly the single rank's work
+    mp.spawn(_worker, args=(world, port, str(tmp_path), ranged), nprocs=world, join=True)
+    pools = [np.load(tmp_path / f"pool_{r}.npy").view(ob.PATCH_DTYPE).reshape(-1) for r in range(world)]
+    n = int(sum(np.load(tmp_path / f"patches_{r}.npy")[0] for r in range(world)))
+    assert n == patches  # the ranks together did exactly the single rank's work
     for f in ("coord", "normal", "ncc", "dscale", "nimages", "images", "nvimages", "vimages"):
-        np.testing.assert_array_equal(p0[f], p1[f], err_msg=f)      # replicated pools stay identical
-        np.testing.assert_array_equal(p0[f], single[f], err_msg=f)  # and equal the 1-rank result
+        for p in pools:
+            np.testing.assert_array_equal(p[f], single[f], err_msg=f)  # replicated pools stay identical and equal the 1-rank result
 
 
 def test_merge_in_view_order():

@@ -32,7 +32,7 @@ def _scene():
 ITERS = 3  # m_depth reaches 2: Optim::check runs, m_vimages / m_vpgrids are exchanged too
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, ranged):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -44,7 +44,8 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc, seeds = _scene()
-    e = engine.Engine(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=5, view_begin=rank, view_stride=world, device=0)
+    shard = dict(shard_index=rank, shard_count=world) if ranged else dict(view_begin=rank, view_stride=world)
+    e = engine.Engine(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=5, device=0, **shard)
     e.set_scene(sc)
     e.upload_patches(seeds)
     hs = mdist.HostStaged(e, torch.device("cuda", 0))
@@ -58,11 +59,14 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_gpu_ranks_equal_one_rank(tmp_path):
+@pytest.mark.parametrize("world,ranged", [(2, False), (3, True)])
+def test_gpu_ranks_equal_one_rank(tmp_path, world, ranged):
+    """world 2 sharded by whole views; world 3 by contiguous job ranges (5 views: views are split between ranks) --
+    what bench.py --gpus N uses."""
     from mvskit_amd import engine
 
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)  # children first: this process has not touched the GPU yet
+    mp.spawn(_worker, args=(world, port, str(tmp_path), ranged), nprocs=world, join=True)  # children first: this process has not touched the GPU yet
     sc, seeds = _scene()
     e = engine.Engine(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=5)
     e.set_scene(sc)
@@ -73,10 +77,9 @@ def test_two_gpu_ranks_equal_one_rank(tmp_path):
         e.update_threshold()
     single = e.patches()
     assert patches > 2000 and single.shape[0] > seeds.shape[0]
-    p0 = np.load(tmp_path / "pool_0.npy").view(engine.PATCH_DTYPE).reshape(-1)
-    p1 = np.load(tmp_path / "pool_1.npy").view(engine.PATCH_DTYPE).reshape(-1)
-    n = int(np.load(tmp_path / "patches_0.npy")[0] + np.load(tmp_path / "patches_1.npy")[0])
+    pools = [np.load(tmp_path / f"pool_{r}.npy").view(engine.PATCH_DTYPE).reshape(-1) for r in range(world)]
+    n = int(sum(np.load(tmp_path / f"patches_{r}.npy")[0] for r in range(world)))
     assert n == patches
     for f in ("coord", "normal", "ncc", "dscale", "nimages", "images", "nvimages", "vimages"):
-        np.testing.assert_array_equal(p0[f], p1[f], err_msg=f)
-        np.testing.assert_array_equal(p0[f], single[f], err_msg=f)
+        for p in pools:
+            np.testing.assert_array_equal(p[f], single[f], err_msg=f)
