@@ -89,3 +89,13 @@ def test_merge_in_view_order():
     counts = [np.array([2, 0, 1, 0, 3]), np.array([0, 1, 0, 2, 0])]
     out = np.concatenate(merge_in_view_order(recs, counts, 5, 2)).ravel()
     np.testing.assert_array_equal(out, [0, 0, 1, 2, 3, 3, 4, 4, 4])
+
+
+def test_merge_in_view_order_split_views():
+    from mvskit_amd.dist import merge_in_view_order
+
+    # 3 views cut into 2 contiguous job ranges: rank 0 holds view 0 and the first part of view 1, rank 1 the rest
+    recs = [np.array([[0], [0], [10], [11]]), np.array([[12], [20], [21]])]
+    counts = [np.array([2, 2, 0]), np.array([0, 1, 2])]
+    out = np.concatenate(merge_in_view_order(recs, counts, 3, 2)).ravel()
+    np.testing.assert_array_equal(out, [0, 0, 10, 11, 12, 20, 21])
