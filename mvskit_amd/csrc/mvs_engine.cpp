@@ -62,7 +62,8 @@ struct mvs_engine {
     int64_t pool_n = 0;
     bool ncc_dirty = false;
     // index
-    DevBuf<int32_t> cnt, start, cursor, ids, vcnt, vstart, vcursor, vids, scan_tmp;
+    DevBuf<int32_t> cnt, start, cursor, vcnt, vstart, vcursor, scan_tmp;
+    DevBuf<unsigned long long> ids, vids;  // list entries of the index build: (descending ncc, id) sort keys
     DevBuf<CellEntry> fat, vfat;
     DevBuf<int32_t> uf_parent, uf_size;  // Filter::filterSmallGroups union-find
     DevBuf<int32_t> cnt_alive, vcnt_alive;
@@ -201,7 +202,7 @@ int build_list(mvs_engine* e, bool vgrid, bool trim) {
     DevBuf<int32_t>& cnt = vgrid ? e->vcnt : e->cnt;
     DevBuf<int32_t>& start = vgrid ? e->vstart : e->start;
     DevBuf<int32_t>& cursor = vgrid ? e->vcursor : e->cursor;
-    DevBuf<int32_t>& ids = vgrid ? e->vids : e->ids;
+    DevBuf<unsigned long long>& ids = vgrid ? e->vids : e->ids;
     DevBuf<CellEntry>& fat = vgrid ? e->vfat : e->fat;
     DevBuf<int32_t>& cnt_alive = vgrid ? e->vcnt_alive : e->cnt_alive;
     HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));

@@ -93,6 +93,14 @@ void launch_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* 
     }
 }
 
+DEV uint32_t sortable_f32(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// list entry of the index build: ascending key order = descending m_ncc, then ascending id (PatchManager::sortPatches)
+__device__ __forceinline__ unsigned long long list_key(float ncc, int64_t id) {
+    return ((unsigned long long)(~sortable_f32(ncc + 0.0f)) << 32) | (unsigned long long)(uint32_t)id;  // + 0.0f: -0 sorts as +0
+}
 // =================================================================== index build
 // cnt[gcell] += 1 for every (patch, view) membership: PatchManager::addPatch, patch_manager.cpp:158-186
 __global__ void k_index_count(DParams prm, int32_t* __restrict__ cnt, int32_t* __restrict__ vcnt) {
@@ -120,13 +128,14 @@ __global__ void k_index_count(DParams prm, int32_t* __restrict__ cnt, int32_t* _
         }
     }
 }
-__global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int32_t* __restrict__ cursor, int32_t* __restrict__ ids,
-                             const int32_t* __restrict__ vstart, int32_t* __restrict__ vcursor, int32_t* __restrict__ vids) {
+__global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int32_t* __restrict__ cursor, unsigned long long* __restrict__ ids,
+                             const int32_t* __restrict__ vstart, int32_t* __restrict__ vcursor, unsigned long long* __restrict__ vids) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= prm.pool_n) return;
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
     const F4 coord = ld4(p->coord);
+    const unsigned long long key = list_key(p->ncc, id);  // the sort key travels with the id: the per-cell sort reads no patch
     const int n = start ? min(p->nimages, MVS_LISTCAP) : 0;
     for (int i = 0; i < n; ++i) {
         const DView* vw = prm.views + p->images[i];
@@ -134,7 +143,7 @@ __global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int
         cell_of(prm, vw, coord, ix, iy);
         if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
         const int g = vw->cell_base + iy * vw->gw + ix;
-        ids[start[g] + atomicAdd(&cursor[g], 1)] = (int32_t)id;
+        ids[start[g] + atomicAdd(&cursor[g], 1)] = key;
     }
     if (vstart) {
         const int nv = min(p->nvimages, MVS_LISTCAP);
@@ -144,47 +153,44 @@ __global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int
             cell_of(prm, vw, coord, ix, iy);
             if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
             const int g = vw->cell_base + iy * vw->gw + ix;
-            vids[vstart[g] + atomicAdd(&vcursor[g], 1)] = (int32_t)id;
+            vids[vstart[g] + atomicAdd(&vcursor[g], 1)] = key;
         }
     }
 }
 // PatchManager::sortPatches (descending NCC; ties by id) per cell, then the MAX_NUM_OF_PATCHES trim
 // (propagate.cpp:94-99,130-135): every cell decides on the same snapshot; a trimmed patch dies everywhere.
-__global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start, int32_t* __restrict__ ids, int do_trim,
+__global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start, unsigned long long* __restrict__ ids, int do_trim,
                                   unsigned long long* __restrict__ trimmed) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= prm.total_cells) return;
     const int b = start[g], e = start[g + 1];
-    for (int i = b + 1; i < e; ++i) {
-        const int id = ids[i];
-        const float ncc = prm.pool[id].ncc;
+    for (int i = b + 1; i < e; ++i) {  // insertion sort, ascending keys
+        const unsigned long long k = ids[i];
         int j = i - 1;
         while (j >= b) {
-            const int o = ids[j];
-            const float on = prm.pool[o].ncc;
-            const bool o_before = (on != ncc) ? (on > ncc) : (o < id);
-            if (o_before) break;
+            const unsigned long long o = ids[j];
+            if (o < k) break;
             ids[j + 1] = o;
             --j;
         }
-        ids[j + 1] = id;
+        ids[j + 1] = k;
     }
     if (do_trim) {
         for (int k = b + prm.cap; k < e; ++k) {
-            const int old = atomicAnd(&prm.pool[ids[k]].flags, ~1);
+            const int old = atomicAnd(&prm.pool[(uint32_t)ids[k]].flags, ~1);
             if (old & 1) atomicAdd(trimmed, 1ull);
         }
     }
 }
 // After the trim: every list is compacted to its alive entries (order kept) and written out "fat".
-__global__ void k_index_finalize(DParams prm, const int32_t* __restrict__ start, const int32_t* __restrict__ ids, CellEntry* __restrict__ fat,
+__global__ void k_index_finalize(DParams prm, const int32_t* __restrict__ start, const unsigned long long* __restrict__ ids, CellEntry* __restrict__ fat,
                                  int32_t* __restrict__ cnt_alive) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= prm.total_cells) return;
     const int b = start[g], e = start[g + 1];
     int n = 0;
     for (int k = b; k < e; ++k) {
-        const int id = ids[k];
+        const int id = (int)(uint32_t)ids[k];
         const DPatch* p = prm.pool + id;
         if (!(p->flags & 1)) continue;
         CellEntry ce;
@@ -196,10 +202,6 @@ __global__ void k_index_finalize(DParams prm, const int32_t* __restrict__ start,
         ++n;
     }
     cnt_alive[g] = n;
-}
-DEV uint32_t sortable_f32(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 // PatchManager::updateDepthMaps, patch_manager.cpp:191-221, over the alive pool (Filter::setDepthMaps, filter.cpp:580-626)
 __global__ void k_depth_maps(DParams prm, unsigned long long* __restrict__ dp) {
@@ -803,13 +805,13 @@ void mvsk_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tm
 void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, cnt, vcnt);
 }
-void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, int32_t* ids, const int32_t* vstart, int32_t* vcursor, int32_t* vids, hipStream_t st) {
+void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, unsigned long long* ids, const int32_t* vstart, int32_t* vcursor, unsigned long long* vids, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, start, cursor, ids, vstart, vcursor, vids);
 }
-void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, int32_t* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
+void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
     hipLaunchKernelGGL(k_index_sort_trim, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, do_trim, trimmed);
 }
-void mvsk_index_finalize(const DParams& prm, const int32_t* start, const int32_t* ids, CellEntry* fat, int32_t* cnt_alive, hipStream_t st) {
+void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* cnt_alive, hipStream_t st) {
     hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, fat, cnt_alive);
 }
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, hipStream_t st) {
