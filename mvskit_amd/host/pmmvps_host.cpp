@@ -467,6 +467,25 @@ extern "C" int mvshost_run(int nviews, int width, int height, const float* P /*[
     return 0;
 }
 
+// The reference's own driver sequence on a dataset directory (test/test.cpp:155-161): Option::init(prefix, "option"),
+// PmMvps::init(option) (cameras txt/%08d.txt, images image/%04d%04d.ppm, masks mask/%08d.pgm), PmMvps::run (seeds from
+// ply/00000000.patch; ply/refined_patches_<iter>.ply written after every iteration).  Returns the final patches.
+extern "C" int mvshost_run_dataset(const char* prefix, int iters, unsigned seed, long long cap, mvs_patch* out, long long* nout) {
+    using namespace mvshost;
+    Option option;
+    if (option.init(prefix, "option") != 0) return MVS_ERR_ARG;
+    PmMvps pmmvps;
+    pmmvps.m_seed = seed; pmmvps.ITER = iters; pmmvps.m_writeFiles = true;
+    if (int r = pmmvps.init(option)) return r;
+    if (int r = pmmvps.run()) return r;
+    pmmvps.m_patchManager.collectPatches();
+    const auto& pp = pmmvps.m_patchManager.m_ppatches;
+    *nout = (long long)pp.size();
+    for (long long i = 0; i < std::min<long long>(cap, (long long)pp.size()); ++i) out[i] = to_record(*pp[i]);
+    pmmvps.m_patchManager.writePatches(std::string(prefix) + "ply/final", false, true, false);  // the .patch text format
+    return 0;
+}
+
 // Option::init on a file: out_i = {nimages, level, csize, wsize, minImageNum, flag, #images}, out_f = {threshold, maxAngle, quad}
 extern "C" int mvshost_option_probe(const char* prefix, const char* option, int* out_i, float* out_f) {
     mvshost::Option o;

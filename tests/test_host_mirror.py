@@ -18,6 +18,7 @@ def host():
     L.mvshost_option_probe.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
     L.mvshost_patch_roundtrip.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p]
     L.mvshost_camera_probe.argtypes = [C.c_char_p, C.c_void_p]
+    L.mvshost_run_dataset.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.c_longlong, C.c_void_p, C.c_void_p]
     L.mvshost_set_ply_output.argtypes = [C.c_char_p]
     L.mvshost_set_ply_output.restype = None
     L.mvshost_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint,
@@ -138,3 +139,51 @@ def test_pmmvps_run_matches_oracle(host, small_plane_scene, tmp_path):
         got = np.array(body[k].split()[6:9], dtype=np.float64)
         assert np.all(np.abs(got - exp) <= 1), (k, got, exp)
         np.testing.assert_allclose(np.array(body[k].split()[:3], dtype=np.float64), rec["coord"][:3], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_dataset_on_disk_equals_in_memory_run(host, small_plane_scene, tmp_path):
+    """The reference's driver sequence on files (test/test.cpp:155-161): option file (option.cpp:35-149), CONTOUR cameras
+    (camera.cpp:27-63,102-141), binary PPM images, seeds in the .patch text format (patch.cpp:31-56,
+    patch_manager.cpp:435-466), PLY / .patch output (patch_manager.cpp:499-633) -- same result as the in-memory run."""
+    sc = small_plane_scene
+    seeds = synth.make_seeds(sc, stride=4, seed=21)
+    root = tmp_path / "data"
+    for d in ("txt", "image", "ply"):
+        (root / d).mkdir(parents=True)
+    (root / "option").write_text(f"# synthetic plane\nlevel 0\ncsize 2\nthreshold 0.7\nwsize 7\nminImageNum 2\nimages -1 0 {sc.nviews}\n")
+    for v in range(sc.nviews):
+        (root / "txt" / f"{v:08d}.txt").write_text("CONTOUR\n" + "\n".join(" ".join(repr(float(x)) for x in row) for row in sc.P[v]) + "\n")
+        with open(root / "image" / f"{v:04d}0000.ppm", "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (sc.W, sc.H))
+            f.write(np.ascontiguousarray(sc.images[v]).tobytes())
+    with open(root / "ply" / "00000000.patch", "w") as f:
+        f.write(f"PATCHES\n{seeds.shape[0]}\n")
+        for r in seeds:
+            f.write("PATCHS\n" + " ".join(repr(float(x)) for x in r["coord"]) + "\n" + " ".join(repr(float(x)) for x in r["normal"]) + "\n")
+            f.write(f"{float(r['ncc'])!r} {float(r['dscale'])!r} {float(r['ascale'])!r}\n{int(r['nimages'])}\n")
+            f.write(" ".join(str(int(x)) for x in r["images"][: r["nimages"]]) + "\n0\n\n")
+    iters = 2
+    cap = 200000
+    out_f = np.zeros(cap, dtype=engine.PATCH_DTYPE)
+    nf = C.c_longlong()
+    assert host.mvshost_run_dataset((str(root) + "/").encode(), iters, 9, cap, out_f.ctypes.data, C.byref(nf)) == 0
+    out_m = np.zeros(cap, dtype=engine.PATCH_DTYPE)
+    nm, ptot = C.c_longlong(), C.c_longlong()
+    P = np.ascontiguousarray(sc.P, dtype=np.float32)
+    img = np.ascontiguousarray(sc.images)
+    sd = np.ascontiguousarray(seeds)
+    assert host.mvshost_run(sc.nviews, sc.W, sc.H, P.ctypes.data, img.ctypes.data, 0, 2, 7, 2, C.c_float(0.7), 9, iters, sd.shape[0], sd.ctypes.data,
+                            cap, out_m.ctypes.data, C.byref(nm), C.byref(ptot)) == 0
+    assert nf.value == nm.value and nf.value > seeds.shape[0]
+    a, b = out_f[: nf.value], out_m[: nm.value]
+    for f in ("coord", "normal", "ncc", "nimages", "images"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    # outputs of PmMvps::run: one PLY per iteration (before and after Filter::run) and the final .patch file
+    for it in range(iters):
+        for name in (f"refined_patches_before_refine_{it}.ply", f"refined_patches_{it}.ply"):
+            head = (root / "ply" / name).read_text().split("\n")[:3]
+            assert head[0] == "ply" and head[2].startswith("element vertex ")
+    txt = (root / "ply" / "final.patch").read_text().split()
+    assert txt[0] == "PATCHES" and int(txt[1]) == nf.value
+    np.testing.assert_allclose([float(x) for x in txt[3:6]], a["coord"][0][:3], rtol=1e-5)
