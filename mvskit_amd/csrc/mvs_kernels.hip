@@ -162,8 +162,8 @@ __global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int
 __global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start, unsigned long long* __restrict__ ids, int do_trim,
                                   unsigned long long* __restrict__ trimmed) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= prm.total_cells) return;
-    const int b = start[g], e = start[g + 1];
+    const bool in = g < prm.total_cells;
+    const int b = in ? start[g] : 0, e = in ? start[g + 1] : 0;
     for (int i = b + 1; i < e; ++i) {  // insertion sort, ascending keys
         const unsigned long long k = ids[i];
         int j = i - 1;
@@ -176,10 +176,14 @@ __global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start
         ids[j + 1] = k;
     }
     if (do_trim) {
+        int mine = 0;
         for (int k = b + prm.cap; k < e; ++k) {
             const int old = atomicAnd(&prm.pool[(uint32_t)ids[k]].flags, ~1);
-            if (old & 1) atomicAdd(trimmed, 1ull);
+            mine += old & 1;
         }
+        // one counter update per wave, not per trimmed patch (a million same-address atomics cost milliseconds)
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(trimmed, (unsigned long long)mine);
     }
 }
 // After the trim: every list is compacted to its alive entries (order kept) and written out "fat".
