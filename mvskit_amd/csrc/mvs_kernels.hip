@@ -262,15 +262,24 @@ __global__ void k_map_extract(DParams prm, int view, int kind, const unsigned lo
 }
 
 // PatchManager::sortPatches head (patch_manager.cpp:411-415): patches with m_ncc < 0 get their score.
+// One wave looks at 64 patches (a lane each) and then scores, one after the other, those that need it: in steady state
+// none does, and the launch is 64 times smaller than one wave per patch.
 __global__ __launch_bounds__(64) void k_fill_ncc(DParams prm, unsigned long long* evals) {
-    const int64_t id = blockIdx.x;
-    DPatch* p = prm.pool + id;
-    if (!(p->flags & 1) || !(p->ncc < 0.0f)) return;
     WaveCtx wc = make_wave_ctx(prm);
-    Cand c;
-    load_cand(p, wc, c);
-    const float ncc = compute_ncc(prm, wc, c.coord, c.normal, c.img, c.nimg);
-    if (wc.lane == 0) { p->ncc = ncc; atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
+    const int64_t mine = (int64_t)blockIdx.x * 64 + wc.lane;
+    bool need = false;
+    if (mine < prm.pool_n) need = (prm.pool[mine].flags & 1) && (prm.pool[mine].ncc < 0.0f);
+    unsigned long long todo = ballot(need);
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        DPatch* p = prm.pool + ((int64_t)blockIdx.x * 64 + l);
+        Cand c;
+        load_cand(p, wc, c);
+        const float ncc = compute_ncc(prm, wc, c.coord, c.normal, c.img, c.nimg);
+        if (wc.lane == 0) p->ncc = ncc;
+    }
+    if (wc.lane == 0 && wc.evals) { atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
 }
 
 // =================================================================== K4: the sweep
@@ -829,7 +838,7 @@ void mvsk_map_extract(const DParams& prm, int view, int kind, const unsigned lon
     hipLaunchKernelGGL(k_map_extract, dim3(nblk(ncells, 256)), dim3(256), 0, st, prm, view, kind, sel, depth, normal, ids, ncells);
 }
 void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_fill_ncc, dim3((unsigned)prm.pool_n), dim3(64), MVS_FRAME_LDS_BYTES, st, prm, evals);
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_fill_ncc, dim3((unsigned)((prm.pool_n + 63) / 64)), dim3(64), MVS_FRAME_LDS_BYTES, st, prm, evals);
 }
 size_t mvsk_sweep_lds_bytes(const DParams& prm) {
     const size_t texs = (size_t)MVS_LISTCAP * 3 * prm.wsz * sizeof(float);  // setRefImage textures: 9408 B at wsize 7
