@@ -1,0 +1,59 @@
+"""Ground truth: the synthetic scenes are analytic (planes + sphere), so every patch can be compared with the surface at
+the pixel of its reference view it projects to.  The reference has no such test (and no fixtures at all);
+this pins the behaviour of the path -- propagation must cover the scene with patches that are closer to the surface than
+the noisy seeds it started from -- independently of the oracle/engine parity."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from mvskit_amd import synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from quality_probe import patch_errors  # noqa: E402
+
+
+def test_oracle_reconstructs_the_plane():
+    sc = synth.make_scene(nviews=3, W=160, H=120, arc_deg=30.0, radius=4.0, kind="plane")
+    seeds = synth.make_seeds(sc, stride=4, seed=5)
+    rel0, ang0 = patch_errors(sc, seeds)
+    o = ob.Oracle(sc.nviews, level=0, csize=2, wsize=7, minImageNum=2, enable_check=0, seed=2, schedule=ob.SCHEDULE_ENGINE,
+                  sum_mode=ob.SUM_TREE64, nthreads=8)
+    o.set_scene(sc)
+    o.add_patches(seeds)
+    for it in range(2):
+        o.propagate(it)
+        o.update_threshold()
+    p = o.patches()
+    made = p[p["dscale"] > 0]
+    assert made.shape[0] > 10 * seeds.shape[0]
+    rel, ang = patch_errors(sc, made)
+    # one pixel of the 160-pixel-wide views is 5e-3 of the depth: the seeds sit 0.3 px off the surface, the patches 0.2 px
+    assert np.median(rel) < 0.7 * np.median(rel0)
+    assert np.median(rel) < 1.5e-3 and np.percentile(rel, 90) < 4e-3
+    assert np.median(ang) < 10.0
+
+
+@pytest.mark.gpu
+def test_engine_reconstructs_the_scene(small_multi_scene):
+    from mvskit_amd import engine
+
+    sc = small_multi_scene
+    seeds = synth.make_seeds(sc, stride=3, seed=19)
+    rel0, _ = patch_errors(sc, seeds)
+    e = engine.Engine(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=3)
+    e.set_scene(sc)
+    e.upload_patches(seeds)
+    for it in range(3):
+        e.propagate(it)
+        e.filter()
+        e.update_threshold()
+    p = e.patches()
+    made = p[p["dscale"] > 0]
+    assert made.shape[0] > 10 * seeds.shape[0]
+    rel, ang = patch_errors(sc, made)
+    assert np.median(rel) < 0.7 * np.median(rel0)
+    assert np.median(rel) < 6e-4 and np.percentile(rel, 90) < 2e-3 and np.percentile(rel, 99) < 8e-3
+    assert np.median(ang) < 8.0 and np.median(made["ncc"]) > 0.95
