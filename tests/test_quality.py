@@ -57,3 +57,25 @@ def test_engine_reconstructs_the_scene(small_multi_scene):
     assert np.median(rel) < 0.7 * np.median(rel0)
     assert np.median(rel) < 6e-4 and np.percentile(rel, 90) < 2e-3 and np.percentile(rel, 99) < 8e-3
     assert np.median(ang) < 8.0 and np.median(made["ncc"]) > 0.95
+
+
+def test_engine_schedule_is_as_good_as_the_reference_order():
+    """The red-black / all-views-at-once ENGINE schedule against the FAITHFUL one (the reference's sequential raster sweep,
+    live lists, minstd_rand0 draws): different patches, the same quality."""
+    sc = synth.make_scene(nviews=3, W=160, H=120, arc_deg=30.0, radius=4.0, kind="plane")
+    seeds = synth.make_seeds(sc, stride=4, seed=5)
+    stats = {}
+    for name, sched, mode in (("faithful", ob.SCHEDULE_FAITHFUL, ob.SUM_SEQ), ("engine", ob.SCHEDULE_ENGINE, ob.SUM_TREE64)):
+        o = ob.Oracle(sc.nviews, level=0, csize=2, wsize=7, minImageNum=2, enable_check=0, seed=2, schedule=sched, sum_mode=mode, nthreads=8)
+        o.set_scene(sc)
+        o.add_patches(seeds)
+        for it in range(2):
+            o.propagate(it)
+            o.update_threshold()
+        p = o.patches()
+        made = p[p["dscale"] > 0]
+        rel, ang = patch_errors(sc, made)
+        stats[name] = (made.shape[0], float(np.median(rel)), float(np.median(ang)))
+        o.close()
+    (nf, rf, af), (ne, re_, ae) = stats["faithful"], stats["engine"]
+    assert ne > 0.5 * nf and re_ < 1.25 * rf and ae < 1.25 * af, stats
