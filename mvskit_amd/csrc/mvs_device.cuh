@@ -1073,8 +1073,11 @@ STAGE int post_process(const DParams& prm, WaveCtx& wc, int* scratch, float* tex
     filter_images_by_angle(prm, wc, scratch, c);
     if (c.nimg < prm.minImageNum) return -1;
     set_grids(prm, wc, c);
+    const int ref_before = rli(c.img, 0);
     set_ref_image(prm, wc, texs, tstride, c);
-    constraint_images(prm, wc, scratch, c, prm.nccThreshold);
+    // Same reference view as before: the second constraintImages would sample the very textures of the first one for
+    // the views that passed it, under the same threshold, and remove nothing.  It runs when the reference changed.
+    if (rli(c.img, 0) != ref_before) constraint_images(prm, wc, scratch, c, prm.nccThreshold);
     if (c.nimg < prm.minImageNum) return -1;
     set_grids(prm, wc, c);
     c.tmp = score2(c, prm.nccThreshold);

@@ -1341,8 +1341,11 @@ int post_process(const Scene& s, Patch& p, const DestCtx* ctx, orc_counters* cnt
     filter_images_by_angle(s, p);
     if (p.nimg < s.cfg.minImageNum) return -1;
     set_grids(s, p);
+    const int ref_before = p.img[0];
     set_ref_image(s, p, cnt);
-    constraint_images(s, p, s.nccThreshold, cnt);
+    /* engine schedule: with the reference view unchanged the second constraintImages would sample the very textures of
+     * the first one for the views that passed it, under the same threshold, and remove nothing -- it is not run */
+    if (s.cfg.schedule != ORC_SCHEDULE_ENGINE || p.img[0] != ref_before) constraint_images(s, p, s.nccThreshold, cnt);
     if (p.nimg < s.cfg.minImageNum) return -1;
     set_grids(s, p);
     p.tmp = score2(p, s.nccThreshold);
