@@ -600,6 +600,20 @@ DEV float compute_incc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int
     if (total == 0.0f) return 2.0f;
     return score / total;
 }
+// tail of Optim::computeINCC (optim.cpp:690-705) on per-view robust INCCs that are already known
+DEV float weighted_incc(const DParams& prm, unsigned okm, float val_l, float weights, int n) {
+    if (n < 2 || !(okm & 1u)) return 2.0f;
+    const int sz = min(prm.tau, n);
+    float score = 0.0f, total = 0.0f;
+    for (int i = 1; i < sz; ++i) {
+        if (!((okm >> i) & 1u)) continue;
+        const float w = rlf(weights, i);
+        total += w;
+        score += rlf(val_l, i) * w;
+    }
+    if (total == 0.0f) return 2.0f;
+    return score / total;
+}
 // PatchManager::computeNcc, patch_manager.cpp:401-404
 DEV float compute_ncc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n) {
     const float w = compute_weights(prm, wc, coord, normal, img, n);
@@ -607,7 +621,7 @@ DEV float compute_ncc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int 
 }
 
 // Optim::setINCCs (vector), optim.cpp:708-746: returns the view-lane INCC array (reference vs every view)
-DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n, int robust) {
+DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n, int robust, unsigned* okm_out = nullptr) {
     const int ref = rli(img, 0);
     F4 px, py;
     get_paxes(prm, prm.views + ref, coord, normal, px, py);
@@ -616,6 +630,7 @@ DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int im
     unsigned okm[1];
     float incc_l;
     eval_core<1, MVS_U1>(prm, wc, f, n, okm, incc_l);
+    if (okm_out) *okm_out = okm[0];
     if (!(okm[0] & 1u)) return 2.0f;
     float incc = robust ? robustincc(incc_l) : incc_l;
     if (wc.lane >= MVS_LISTCAP || !((okm[0] >> (wc.lane & 31)) & 1u)) incc = 2.0f;
@@ -661,8 +676,13 @@ DEV void add_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c
 }
 
 // Optim::constraintImages, optim.cpp:207-219
-DEV void constraint_images(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c, float nccThreshold) {
-    const float inccs = set_inccs(prm, wc, c.coord, c.normal, c.img, c.nimg, 0);
+// keep_n > 0 (first constraintImages of postProcess inside the sweep): refinePatch left the final m_ncc to this
+// evaluation -- computeINCC at the refined patch samples the first min(tau, keep_n) of these very textures -- so it is
+// taken here, as the tail of computeINCC over the robust INCCs of those views with the weights refinePatch computed.
+DEV void constraint_images(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c, float nccThreshold, float keep_w = 0.0f, int keep_n = 0) {
+    unsigned okm = 0u;
+    const float inccs = set_inccs(prm, wc, c.coord, c.normal, c.img, c.nimg, 0, &okm);
+    if (keep_n > 0) c.ncc = 1.0f - unrobustincc(weighted_incc(prm, okm, robustincc(inccs), keep_w, keep_n));
     const bool keep = wc.lane == 0 || (wc.lane < c.nimg && inccs < 1.0f - nccThreshold);
     c.nimg = compact1(scratch, wc, keep, c.img);
 }
@@ -860,7 +880,8 @@ DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
     }
 }
 // Optim::refinePatch, optim.cpp:480-547, BOBYQA replaced by the halving random search
-STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+// w_out != nullptr (inside the sweep): the weights go out and the final m_ncc is left to postProcess
+STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, float* w_out = nullptr) {
     RefineCtx rc;
     rc.center = c.coord;
     rc.ref = rli(c.img, 0);
@@ -900,7 +921,8 @@ STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, u
     x[0] = bx0; x[1] = bx1; x[2] = bx2;
     decode(prm, rc, x[0], x[1], x[2], c.coord, c.normal);
     c.normal.w = 0.0f;
-    c.ncc = 1.0f - unrobustincc(compute_incc(prm, wc, c.coord, c.normal, c.img, c.nimg, w, 1));
+    if (w_out) *w_out = w;
+    else c.ncc = 1.0f - unrobustincc(compute_incc(prm, wc, c.coord, c.normal, c.img, c.nimg, w, 1));
 }
 
 // ------------------------------------------------------------------ post-processing
@@ -1065,11 +1087,12 @@ DEV int get_mask_all(const DParams& prm, const WaveCtx& wc, const Cand& c) {
 DEV float score2(const Cand& c, float thr) { return fmaxf(0.0f, c.ncc - thr) * (float)c.nimg; }
 
 // Optim::postProcess, optim.cpp:260-298 (Optim::check is applied by the caller, which owns the cell lists)
-STAGE int post_process(const DParams& prm, WaveCtx& wc, int* scratch, float* texs, int tstride, Cand& c) {
+STAGE int post_process(const DParams& prm, WaveCtx& wc, int* scratch, float* texs, int tstride, Cand& c, float keep_w = 0.0f, bool keep = false) {
     if (c.nimg < prm.minImageNum) return -1;
     if (get_mask_all(prm, wc, c) == 0) return -1;
+    const int keep_n = keep ? c.nimg : 0;
     add_images(prm, wc, scratch, c);
-    constraint_images(prm, wc, scratch, c, prm.nccThreshold);
+    constraint_images(prm, wc, scratch, c, prm.nccThreshold, keep_w, keep_n);
     filter_images_by_angle(prm, wc, scratch, c);
     if (c.nimg < prm.minImageNum) return -1;
     set_grids(prm, wc, c);

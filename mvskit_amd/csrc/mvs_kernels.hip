@@ -405,9 +405,10 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
                 const int pre_r = pre_process(prm, wc, s_scratch, c);
                 ST_ADD(2, st_t)
                 if (pre_r == -1) { ++n_f0; continue; }
-                refine_patch(prm, wc, c, k0, k1, k2, k3);
+                float keep_w;  // computeWeights of refinePatch, for the m_ncc postProcess takes from its first evaluation
+                refine_patch(prm, wc, c, k0, k1, k2, k3, &keep_w);
                 ST_ADD(3, st_t)
-                const int post_r = post_process(prm, wc, s_scratch, s_texs, tstride, c);
+                const int post_r = post_process(prm, wc, s_scratch, s_texs, tstride, c, keep_w, true);
                 ST_ADD(4, st_t)
                 if (post_r == -1) { ++n_f1; continue; }
                 if (prm.depth >= 2 && prm.enable_check) {  // Optim::check, optim.cpp:292

@@ -565,17 +565,20 @@ float compute_ncc(const Scene& s, const Patch& p, orc_counters* cnt) {
 }
 
 /* Optim::setINCCs (vector), optim.cpp:708-746: reference view against ALL listed views (D9) */
-void set_inccs(const Scene& s, const Patch& p, const int* idx, int n, int robust, float* inccs, orc_counters* cnt) {
+void set_inccs(const Scene& s, const Patch& p, const int* idx, int n, int robust, float* inccs, orc_counters* cnt, unsigned* okmask = nullptr) {
     V4 px, py;
     get_paxes(s, idx[0], p.coord, p.normal, px, py);
     if (cnt) cnt->evals++;
     Tex t0, ti;
+    if (okmask) *okmask = 0u;
     if (get_tex(s, p.coord, px, py, p.normal, idx[0], t0, cnt) == 0) normalize_tex(s, t0);
     if (!t0.ok) { for (int i = 0; i < n; ++i) inccs[i] = 2.0f; return; }
     inccs[0] = 0.0f;
+    if (okmask) *okmask = 1u;
     for (int i = 1; i < n; ++i) {
         if (get_tex(s, p.coord, px, py, p.normal, idx[i], ti, cnt) == 0) normalize_tex(s, ti);
         if (!ti.ok) { inccs[i] = 2.0f; continue; }
+        if (okmask) *okmask |= 1u << i;
         const float d = 1.0f - dot_tex(s, t0, ti);
         inccs[i] = robust ? robustincc(d) : d;
     }
@@ -650,9 +653,27 @@ void add_images(const Scene& s, Patch& p) {
 }
 
 /* Optim::constraintImages, optim.cpp:207-219 */
-void constraint_images(const Scene& s, Patch& p, float nccThreshold, orc_counters* cnt) {
+/* w_keep / n_keep (engine schedule, first constraintImages of postProcess): refinePatch left the final m_ncc to this
+ * evaluation -- computeINCC at the refined patch samples the first min(tau, n_keep) of these very textures -- so it is
+ * taken here as the tail of computeINCC (optim.cpp:690-705) over the robust INCCs of those views */
+void constraint_images(const Scene& s, Patch& p, float nccThreshold, orc_counters* cnt, const float* w_keep = nullptr, int n_keep = 0) {
     float inccs[MAXI];
-    set_inccs(s, p, p.img, p.nimg, 0, inccs, cnt);
+    unsigned ok = 0;
+    set_inccs(s, p, p.img, p.nimg, 0, inccs, cnt, &ok);
+    if (w_keep) {
+        float incc = 2.0f;
+        if (n_keep >= 2 && (ok & 1u)) {
+            const int sz = std::min(s.tau, n_keep);
+            float score = 0.0f, total = 0.0f;
+            for (int i = 1; i < sz; ++i) {
+                if (!((ok >> i) & 1u)) continue;
+                total += w_keep[i];
+                score += robustincc(inccs[i]) * w_keep[i];
+            }
+            if (total != 0.0f) incc = score / total;
+        }
+        p.ncc = 1.0f - unrobustincc(incc);
+    }
     int n = 1;
     for (int i = 1; i < p.nimg; ++i) if (inccs[i] < 1.0f - nccThreshold) p.img[n++] = p.img[i];
     p.nimg = n;
@@ -821,7 +842,9 @@ double cost_func(const Scene& s, const RefineCtx& rc, const int* idx, int n, con
  * halving random search: K steps, per step 3 proposals around the step's start point
  * (depth only / angles only / both), the step's best is kept if it improves; ranges halve.
  * Same variables, same bounds (angles +-23.99999 units of pi/48, depth unbounded). */
-int refine_patch(const Scene& s, Patch& p, const uint32_t key[4], orc_counters* cnt) {
+/* w_keep != nullptr (engine schedule inside propagatePatch): the weights go out and the final m_ncc is left to the first
+ * constraintImages of postProcess, which samples the same textures anyway */
+int refine_patch(const Scene& s, Patch& p, const uint32_t key[4], orc_counters* cnt, float* w_keep = nullptr) {
     RefineCtx rc;
     rc.center = p.coord;
     rc.ref = p.img[0];
@@ -858,7 +881,8 @@ int refine_patch(const Scene& s, Patch& p, const uint32_t key[4], orc_counters* 
     }
     decode(s, rc, x, p.coord, p.normal); /* optim.cpp:535-539 */
     p.normal.w = 0.0f;
-    p.ncc = 1.0f - unrobustincc(compute_incc(s, p.coord, p.normal, p.img, p.nimg, w, 1, cnt));
+    if (w_keep) { for (int i = 0; i < MAXI; ++i) w_keep[i] = i < p.nimg ? w[i] : 0.0f; }
+    else p.ncc = 1.0f - unrobustincc(compute_incc(s, p.coord, p.normal, p.img, p.nimg, w, 1, cnt));
     return 0;
 }
 
@@ -1333,11 +1357,12 @@ int get_mask_all(const Scene& s, const V4& coord) {
 }
 
 /* Optim::postProcess, optim.cpp:260-298 */
-int post_process(const Scene& s, Patch& p, const DestCtx* ctx, orc_counters* cnt) {
+int post_process(const Scene& s, Patch& p, const DestCtx* ctx, orc_counters* cnt, const float* w_keep = nullptr) {
     if (p.nimg < s.cfg.minImageNum) return -1;
     if (get_mask_all(s, p.coord) == 0) return -1;
+    const int n_keep = p.nimg;
     add_images(s, p);
-    constraint_images(s, p, s.nccThreshold, cnt);
+    constraint_images(s, p, s.nccThreshold, cnt, w_keep, n_keep);
     filter_images_by_angle(s, p);
     if (p.nimg < s.cfg.minImageNum) return -1;
     set_grids(s, p);
@@ -1628,8 +1653,9 @@ void propagate_patch_engine(const Scene& s, DestCtx& ctx, int src, int image, in
         }
         cnt.patches++;
         if (pre_process(s, cand, &cnt) == -1) { cnt.fail0++; continue; }
-        refine_patch(s, cand, key, &cnt);
-        if (post_process(s, cand, &ctx, &cnt) == -1) { cnt.fail1++; continue; }
+        float w_keep[MAXI];
+        refine_patch(s, cand, key, &cnt, w_keep);
+        if (post_process(s, cand, &ctx, &cnt, w_keep) == -1) { cnt.fail1++; continue; }
         if (np == s.cap) { /* removePatch(worst), propagate.cpp:198-201 */
             ctx.list.erase(ctx.list.begin() + (s.cap - 1));
             if (worst >= NEWBASE) ctx.staged[worst - NEWBASE].alive = false;
