@@ -236,7 +236,7 @@ def main():
                                "algorithmic_bytes_per_launch": alg / max(launches, 1),
                                "index_ms": index_ms, "commit_ms": commit_ms, "sweep_ms": sweep_ms,
                                "note": "achieved = 588 B x view evaluations counted on the device / HIP-event time of k_sweep; the kernel is bound by VALU "
-                                       "issue (85 % of SIMD time, DESIGN.md section 5), and the 131 MB of pyramids sit in the Infinity Cache"}
+                                       "issue (over 90 % of SIMD time, DESIGN.md section 5), and the 131 MB of pyramids sit in the Infinity Cache"}
             if ex is not None:
                 out["roofline"]["rank"] = 0
                 out["exchange"] = {"ms": exchange_ms, "bytes_gathered_per_rank": exchange_bytes, "collective": "all_gather_into_tensor (RCCL)",
