@@ -1370,7 +1370,7 @@ int post_process(const Scene& s, Patch& p, const DestCtx* ctx, orc_counters* cnt
     set_ref_image(s, p, cnt);
     /* engine schedule: with the reference view unchanged the second constraintImages would sample the very textures of
      * the first one for the views that passed it, under the same threshold, and remove nothing -- it is not run */
-    if (s.cfg.schedule != ORC_SCHEDULE_ENGINE || p.img[0] != ref_before) constraint_images(s, p, s.nccThreshold, cnt);
+    if (s.cfg.schedule != ORC_SCHEDULE_ENGINE || s.cfg.literal_evals || p.img[0] != ref_before) constraint_images(s, p, s.nccThreshold, cnt);
     if (p.nimg < s.cfg.minImageNum) return -1;
     set_grids(s, p);
     p.tmp = score2(p, s.nccThreshold);
@@ -1641,7 +1641,7 @@ void propagate_patch_engine(const Scene& s, DestCtx& ctx, int src, int image, in
             const float a = rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], 0) * s.cfg.csize;
             const float b = rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], 1) * s.cfg.csize;
             const V3 nic{icoord.x + a, icoord.y + b, 1.0f};
-            if (!generate_patch(s, srcp, nic, cand, &cnt, as_image, false)) continue;
+            if (!generate_patch(s, srcp, nic, cand, &cnt, as_image, s.cfg.literal_evals != 0)) continue;
             cnt.candidates++;
         } else {
             worst = ctx.list[s.cap - 1];
@@ -1654,8 +1654,9 @@ void propagate_patch_engine(const Scene& s, DestCtx& ctx, int src, int image, in
         cnt.patches++;
         if (pre_process(s, cand, &cnt) == -1) { cnt.fail0++; continue; }
         float w_keep[MAXI];
-        refine_patch(s, cand, key, &cnt, w_keep);
-        if (post_process(s, cand, &ctx, &cnt, w_keep) == -1) { cnt.fail1++; continue; }
+        float* const wk = s.cfg.literal_evals ? nullptr : w_keep;  /* literal: refinePatch evaluates its own final m_ncc */
+        refine_patch(s, cand, key, &cnt, wk);
+        if (post_process(s, cand, &ctx, &cnt, wk) == -1) { cnt.fail1++; continue; }
         if (np == s.cap) { /* removePatch(worst), propagate.cpp:198-201 */
             ctx.list.erase(ctx.list.begin() + (s.cap - 1));
             if (worst >= NEWBASE) ctx.staged[worst - NEWBASE].alive = false;

@@ -68,6 +68,10 @@ typedef struct orc_config {
     int32_t view_propagation; /* engine schedule only: the disabled branch of propagate.cpp:110-120 (see dest_cell_engine) */
     int32_t shard_index;  /* engine schedule, shard_count > 1: sweep the shard_index-th of shard_count contiguous ranges */
     int32_t shard_count;  /*   of the destination cells of all views (view_begin / view_stride ignored) */
+    int32_t literal_evals; /* engine schedule only, 1 = no evaluation shortcuts: the initial m_ncc of every candidate
+                            * (propagate.cpp:235), refinePatch's own final computeINCC (optim.cpp:541) and the second
+                            * constraintImages of postProcess (optim.cpp:286) are always evaluated, as the reference does.
+                            * The patches must come out identical; only the work counters (evals, view_evals) differ. */
 } orc_config;
 
 typedef struct orc_counters {

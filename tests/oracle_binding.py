@@ -30,7 +30,8 @@ class Config(C.Structure):
                 ("seed", C.c_uint32), ("schedule", C.c_int32), ("sum_mode", C.c_int32), ("refine_steps", C.c_int32),
                 ("refine_rd0", C.c_float), ("refine_ra0", C.c_float), ("enable_check", C.c_int32),
                 ("view_begin", C.c_int32), ("view_stride", C.c_int32), ("nthreads", C.c_int32),
-                ("view_propagation", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32)]
+                ("view_propagation", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
+                ("literal_evals", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -55,9 +56,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MVS_ORACLE_LIB", LIB_PATH)  # `make -C oracle asan-test` points this at the sanitizer build
+    if path == LIB_PATH and not os.path.exists(LIB_PATH):
         build()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, f32p, u8p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
     L.orc_default_config.argtypes = [C.POINTER(Config)]
     L.orc_create.argtypes = [C.POINTER(Config)]

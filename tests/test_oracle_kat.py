@@ -256,3 +256,34 @@ def test_view_propagation_option(small_plane_scene):
     assert set(np.unique(res[(0, 1)][1]["images"][:, 0])) <= set(np.unique(res[(1, 1)][1]["images"][:, 0]))
     assert res[(1, 1)][0] == res[(1, 4)][0]
     np.testing.assert_array_equal(res[(1, 1)][1]["coord"], res[(1, 4)][1]["coord"])
+
+
+def test_engine_shortcuts_leave_patches_identical(small_multi_scene):
+    """The three evaluation shortcuts of the ENGINE schedule (lazy initial m_ncc of a candidate,
+    final m_ncc of refinePatch taken from postProcess's first constraintImages, second constraintImages only after a
+    change of reference view) against the literal evaluation order of the reference (propagate.cpp:235, optim.cpp:541,
+    optim.cpp:286; orc_config.literal_evals = 1): three iterations of PmMvps::run's loop with Optim::check, pools byte
+    for byte identical after every iteration; only the work counters may differ."""
+    sc = small_multi_scene
+    seeds = synth.make_seeds(sc, stride=4, seed=17)
+    kw = dict(level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64, enable_check=1, seed=13, nthreads=8)
+    short = ob.Oracle(sc.nviews, literal_evals=0, **kw)
+    lit = ob.Oracle(sc.nviews, literal_evals=1, **kw)
+    for o in (short, lit):
+        o.set_scene(sc)
+        o.add_patches(seeds)
+    saved = 0
+    for it in range(3):
+        cs, cl = short.propagate(it), lit.propagate(it)
+        for k in ("candidates", "prefiltered", "patches", "fail0", "fail1", "inserted", "replaced", "trimmed"):
+            assert cs[k] == cl[k], (it, k, cs, cl)
+        assert cs["evals"] < cl["evals"] and cs["view_evals"] < cl["view_evals"]
+        saved += cl["evals"] - cs["evals"]
+        ps, pl = short.patches(), lit.patches()
+        assert ps.shape == pl.shape and ps.shape[0] > 0
+        assert ps.tobytes() == pl.tobytes(), f"pools differ after iteration {it}"
+        short.update_threshold()
+        lit.update_threshold()
+    assert saved > 1000
+    short.close()
+    lit.close()
