@@ -2,11 +2,15 @@
 """bench.py -- patches/s of the propagate+optim iteration on a 12-view 1920x1080 synthetic scene.
 
 One "step" = one Propagate::run(iter) (pmmvps/propagate.cpp:28-64) over all views: two colour passes, each an
-index build + the sweep kernel + the commit, followed by PmMvps::updateThreshold (pmmvps.cpp:70-74).
-`value` = patches (candidates that reached Optim::preProcess, propagate.cpp:182) of all ranks / wall time of
-the K timed steps (max over ranks), inputs resident in HBM.  See DESIGN.md "Measurement".
+index build + the sweep kernel + the commit, followed by PmMvps::updateThreshold and ++m_depth (pmmvps.cpp:70-74,105).
+The steps walk the schedule of PmMvps::run (pmmvps.cpp:90-105): iterations 0, 1, 2 with nccThreshold 0.7 / 0.65 / 0.6 and
+m_depth 1 / 2 / 3, then the state is reset (pool cleared, seeds uploaded again, thresholds back) OUTSIDE the timed region
+and the schedule starts over -- so any --steps measures BASELINE.json configs[1] ("3 iterations") and the thresholds never
+leave [0.6, 0.7].  `value` = patches (candidates that reached Optim::preProcess, propagate.cpp:182) of all ranks /
+time of the K timed steps (max over ranks), inputs resident in HBM.  See DESIGN.md "Measurement".
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...              (spawns N rank processes itself)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 from __future__ import annotations
@@ -14,6 +18,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,6 +28,8 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_VIEW_EVAL = 588  # 49 samples x 4 texels x 3 B (optim.cpp:835-842 x image.cpp:462-470), SURVEY.md 8d
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+SCHEDULE_ITERS = 3             # ITER of PmMvps::run, pmmvps.cpp:90
+NCC0, NCC_BEFORE0, DEPTH0 = 0.7, 0.4, 1  # Option::m_nccThreshold, nccThreshold - 0.3 (pmmvps.cpp:57), m_depth after createPatches (pmmvps.cpp:85)
 
 
 def log(*a):
@@ -38,11 +46,28 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--seed-stride", type=int, default=2, help="one seed patch per stride x stride cells per view")
     ap.add_argument("--refine-steps", type=int, default=8)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--filter", action="store_true", help="BASELINE config 5: run Filter::run (filter.cpp:25-49) after every iteration, inside the timed region")
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal: run the N>1 code path (RCCL exchange) with a world of 1")
     ap.add_argument("--scene-cache", default=os.path.join("/tmp", "mvskit_scene_cache"))
     return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters, so nothing that has
+    touched the GPU is ever re-executed) and wait for them.  Rank 0 prints the JSON line on the inherited stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def load_scene(args, rank):
@@ -69,27 +94,44 @@ def load_scene(args, rank):
     return sc, seeds
 
 
-def cpu_baseline(args, sc, seeds):
+def cpu_baseline(args, sc, seeds, pool_after_iter0, gpu_patches_by_iter):
     """The oracle (oracle/pmmvs_oracle.cpp) in its FAITHFUL schedule -- sequential raster sweep, one thread, the
-    reference's execution model -- on a bounded sample of the same workload: the first source cells of view 0
-    in raster order until about --cpu-seconds have passed."""
+    reference's execution model -- on two bounded samples of the same workload, so that the work mix is the GPU's:
+      A. iteration 0 (m_depth 1, no Optim::check) from the seeds;
+      B. iteration 1 (m_depth 2, nccThreshold 0.65, Optim::check active) from the pool the GPU held after iteration 0.
+    Each runs the source cells of view 0 in sweep order until half of --cpu-seconds has passed.  The reported rate weights
+    the two by the GPU's own patch counts (iteration 0 -> A; iterations 1, 2 -> B)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
-    o = ob.Oracle(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_FAITHFUL, sum_mode=ob.SUM_SEQ,
-                  enable_check=0, refine_steps=args.refine_steps, seed=1)
-    o.set_scene(sc)
-    o.add_patches(seeds)
-    o.set_time_budget(args.cpu_seconds)
-    t0 = time.perf_counter()
-    c = o.propagate(0)
-    spent = time.perf_counter() - t0
-    patches, evals = c["patches"], c["view_evals"]
-    o.close()
-    res = {"value": patches / spent if spent > 0 else 0.0, "unit": "patches/s", "cores": 1, "kind": "port",
-           "sample": f"oracle faithful schedule, single thread, the source cells of view 0 in raster order (iteration 0) of the same scene until {args.cpu_seconds:.0f} s had passed: "
-                     f"{patches} patches, {evals} view evaluations in {spent:.1f} s",
-           "view_evals_per_s": evals / spent if spent > 0 else 0.0}
+    half = max(1.0, args.cpu_seconds / 2)
+    kw = dict(level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_FAITHFUL, sum_mode=ob.SUM_SEQ, refine_steps=args.refine_steps, seed=1)
+    samples = []
+    for name, it, recs, check in (("A", 0, seeds, 0), ("B", 1, pool_after_iter0, 1)):
+        if recs is None:
+            continue
+        o = ob.Oracle(sc.nviews, enable_check=check, **kw)
+        o.set_scene(sc)
+        o.add_patches(recs)
+        for _ in range(it):
+            o.update_threshold()
+        o.set_time_budget(half)
+        t0 = time.perf_counter()
+        c = o.propagate(it)
+        spent = time.perf_counter() - t0
+        o.close()
+        samples.append({"name": name, "iter": it, "patches": c["patches"], "view_evals": c["view_evals"], "seconds": spent,
+                        "rate": c["patches"] / spent if spent > 0 else 0.0})
+        log(f"cpu sample {name}: {c['patches']} patches, {c['view_evals']} view evaluations in {spent:.1f} s")
+    wa = gpu_patches_by_iter[0]
+    wb = sum(gpu_patches_by_iter[1:]) if len(samples) > 1 else 0
+    sec_per_patch = (wa / samples[0]["rate"] + (wb / samples[1]["rate"] if wb else 0.0)) / max(wa + wb, 1)
+    res = {"value": 1.0 / sec_per_patch if sec_per_patch > 0 else 0.0, "unit": "patches/s", "cores": 1, "kind": "port",
+           "sample": f"oracle faithful schedule, one thread, same scene, source cells of view 0 in sweep order for {half:.0f} s each: "
+                     + "; ".join(f"{s['name']} = iteration {s['iter']} ({'seeds, m_depth 1' if s['iter'] == 0 else 'the pool of the GPU run after iteration 0, m_depth 2, Optim::check on'}): "
+                                 f"{s['patches']} patches in {s['seconds']:.1f} s = {s['rate']:.0f} patches/s" for s in samples)
+                     + f"; weighted by the GPU run's patches per iteration {gpu_patches_by_iter}",
+           "view_evals_per_s": sum(s["view_evals"] for s in samples) / max(sum(s["seconds"] for s in samples), 1e-9)}
     # SURVEY 8(d) asks for the all-core figure as well: the engine schedule (what the GPU runs), OpenMP over the
     # destination cells of one colour pass, every host core this process may use
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -98,19 +140,21 @@ def cpu_baseline(args, sc, seeds):
                   enable_check=0, refine_steps=args.refine_steps, seed=1, nthreads=cores)
     o.set_scene(sc)
     o.add_patches(seeds)
-    o.set_time_budget(max(1.0, args.cpu_seconds / 2))
-    t0 = time.perf_counter()
+    o.set_time_budget(max(1.0, args.cpu_seconds / 3))
     c = o.engine_pass(0, 1)  # the seeds sit on even cells: their destinations have colour 1
     spent = o.last_sweep_seconds()  # the parallel sweep alone; the (serial) index build before it is not counted
     o.close()
     res["all_cores"] = {"value": c["patches"] / spent if spent > 0 else 0.0, "unit": "patches/s", "cores": cores,
-                        "sample": f"oracle engine schedule, OpenMP over destination cells, colour pass 1 of iteration 0 until {max(1.0, args.cpu_seconds / 2):.0f} s "
+                        "sample": f"oracle engine schedule, OpenMP over destination cells, colour pass 1 of iteration 0 until {max(1.0, args.cpu_seconds / 3):.0f} s "
                                   f"had passed: {c['patches']} patches in {spent:.1f} s"}
     return res
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))  # nothing has touched the GPU in this process
+
     import numpy as np
     import torch
 
@@ -118,25 +162,34 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    shared_gpu = world > ndev  # rehearsal on a box with fewer GPUs than ranks: RCCL refuses two ranks on one device
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or args.force_exchange:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if world > 1:
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        elif world > 1:
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend="nccl", device_id=device, rank=0, world_size=1)
 
     from mvskit_amd import engine as eng
-    from mvskit_amd.dist import DeviceExchange
+    from mvskit_amd import dist as mdist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     if rank == 0:
         sc, seeds = load_scene(args, rank)
@@ -146,16 +199,31 @@ def main():
         sc, seeds = load_scene(args, rank)
 
     e = eng.Engine(args.views, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=1, refine_steps=args.refine_steps,
-                   shard_index=rank, shard_count=world, device=local_rank)
+                   shard_index=rank, shard_count=world, device=dev_index, nccThreshold=NCC0, depth=DEPTH0)
     if rank == 0:
-        log(f"scene ready: {sc.nviews} views {sc.W}x{sc.H}, {seeds.shape[0]} seeds")
+        log(f"scene ready: {sc.nviews} views {sc.W}x{sc.H}, {seeds.shape[0]} seeds; world {world}" + (" (ranks share a GPU: host-staged exchange over gloo)" if shared_gpu else ""))
     e.set_scene(sc)
-    e.upload_patches(seeds)
-    ex = DeviceExchange(device) if (world > 1 or args.force_exchange) else None
+    exchange = "none"
+    ex = None
+    if world > 1 or args.force_exchange:
+        if shared_gpu:
+            ex = mdist.HostStagedExchange(e, device, sc.nviews)
+            exchange = "host-staged all-gather over gloo (rehearsal: ranks share one GPU)"
+        else:
+            ex = mdist.EngineExchange(e, device)
+            exchange = ex.description
+
+    def reset_state():
+        """PmMvps::init thresholds + DepthNormInit::createPatches (pmmvps.cpp:54-67,83-85): outside the timed region."""
+        e.clear_patches()
+        e.upload_patches(seeds)
+        e.set_thresholds(NCC0, NCC_BEFORE0, DEPTH0)
 
     def step(it):
         ts = time.perf_counter()
-        c = ex.propagate(e, it) if ex else e.propagate(it)
+        thr = e.thresholds()
+        assert 0.6 - 1e-4 <= thr[0] <= 0.7 + 1e-4 and 1 <= thr[2] <= SCHEDULE_ITERS, thr
+        c = ex.propagate(it) if ex else e.propagate(it)
         t = dict(ex.last_timing) if ex else e.timing()
         if args.filter:
             tf = time.perf_counter()
@@ -163,34 +231,41 @@ def main():
             t["filter_ms"] = 1000.0 * (time.perf_counter() - tf)
         e.update_threshold()
         if rank == 0:
-            log(f"iter {it}: {time.perf_counter() - ts:.3f} s, patches {c['patches']}, candidates {c['candidates']}, view_evals {c['view_evals']}, "
-                f"inserted {c['inserted']}, replaced {c['replaced']}, timing {t}" + (f", filter removed {c['filter_removed']}" if args.filter else ""))
+            log(f"iter {it} (nccThreshold {thr[0]:.2f}, m_depth {thr[2]}): {time.perf_counter() - ts:.3f} s, patches {c['patches']}, candidates {c['candidates']}, "
+                f"view_evals {c['view_evals']}, inserted {c['inserted']}, replaced {c['replaced']}, timing {t}" + (f", filter removed {c['filter_removed']}" if args.filter else ""))
         return c, t
 
-    it = 0
-    for _ in range(args.warmup):
-        step(it)
-        it += 1
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    # warm-up: W steps of the same schedule
+    for s in range(args.warmup):
+        if s % SCHEDULE_ITERS == 0:
+            reset_state()
+        step(s % SCHEDULE_ITERS)
+
     patches = view_evals = evals = 0
     sweep_ms = index_ms = commit_ms = exchange_ms = 0.0
     launches = exchange_bytes = local_view_evals = 0
-    for _ in range(args.steps):
+    patches_by_iter = [0] * SCHEDULE_ITERS
+    pool_after_iter0 = None
+    timed = 0.0
+    for s in range(args.steps):
+        it = s % SCHEDULE_ITERS
+        if it == 0:
+            reset_state()  # untimed: the clock runs only around the steps
+        barrier()
+        t0 = time.perf_counter()
         c, t = step(it)
-        it += 1
+        barrier()
+        timed += time.perf_counter() - t0
         patches += c["patches"]; view_evals += c["view_evals"]; evals += c["evals"]
+        patches_by_iter[it] += c["patches"]
         sweep_ms += t["sweep_ms"]; index_ms += t["index_ms"]; commit_ms += t["commit_ms"]; launches += t["sweep_launches"]
         exchange_ms += t.get("exchange_ms", 0.0); exchange_bytes += t.get("exchange_bytes", 0)
         local_view_evals += c["view_evals"]
-    torch.cuda.synchronize()
+        if it == 0 and pool_after_iter0 is None and world == 1 and args.cpu_seconds > 0 and not args.filter:
+            pool_after_iter0 = e.patches()  # for the CPU baseline's sample B (untimed: after the closing barrier)
+    dt = timed
     if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt, float(patches), float(view_evals)], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt, float(patches), float(view_evals)], dtype=torch.float64, device="cpu" if shared_gpu else device)
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tt.clone()
@@ -199,6 +274,7 @@ def main():
     n_alive = e.num_patches()
 
     if rank == 0:
+        reps, extra = divmod(args.steps, SCHEDULE_ITERS)
         out = {
             "metric": "patches/s (propagate+optim iteration), 12-view 1080p",
             "value": patches / dt,
@@ -212,39 +288,46 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.views}-view {args.width}x{args.height} synthetic scene (3 planes + sphere), level 0, csize 2, wsize 7, "
-                                   f"minImageNum 3, 1 seed per {args.seed_stride}x{args.seed_stride} cells per view, {args.steps} iterations after {args.warmup} warm-up",
-                       "views": args.views, "width": args.width, "height": args.height, "csize": 2, "wsize": 7,
-                       "refine_evals": 1 + 3 * args.refine_steps, "check_depth2": True, "filter_run": bool(args.filter),
-                       "parallelism": "single GPU" if world == 1 else f"the (view, cell) sequence sharded in {world} contiguous ranges over {world} GPUs, RCCL all-gather of patch records per colour pass"},
+            "config": {"workload": f"{args.views}-view {args.width}x{args.height} synthetic scene (3 planes + sphere), level 0, csize 2, wsize 7, minImageNum 3, "
+                                   f"1 seed per {args.seed_stride}x{args.seed_stride} cells per view; the 3-iteration schedule of PmMvps::run (nccThreshold 0.70/0.65/0.60, "
+                                   f"m_depth 1/2/3, Optim::check from m_depth 2) run {reps} time(s)" + (f" + its first {extra} iteration(s)" if extra else "")
+                                   + f" = {args.steps} timed steps after {args.warmup} warm-up step(s); pool and thresholds reset between repetitions outside the timed region",
+                       "views": args.views, "width": args.width, "height": args.height, "csize": 2, "wsize": 7, "iterations_per_repetition": SCHEDULE_ITERS,
+                       "repetitions": reps, "extra_iterations": extra, "refine_evals": 1 + 3 * args.refine_steps, "check_depth2": True, "filter_run": bool(args.filter),
+                       "parallelism": "single GPU" if world == 1 else f"the (view, cell) sequence sharded in {world} contiguous ranges over {world} ranks; per colour pass: {exchange}"},
             "patches": patches,
+            "patches_by_iteration": patches_by_iter if world == 1 else None,
             "view_evals": view_evals,
             "pool_alive": n_alive,
         }
         if sweep_ms > 0:
             alg = local_view_evals * ALG_BYTES_PER_VIEW_EVAL  # rank 0's own launches (= the whole job at N = 1)
             ach = alg / (sweep_ms * 1e-3) / 1e9
-            traffic = None
+            traffic = traffic_from = None
             prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(prof):
                 try:
-                    traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                    pj = json.load(open(prof))
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_from = f"profiles/pmc_traffic.json ({pj.get('command', 'separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}); not measured in this run"
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_from": traffic_from,
                                "kernel": "k_sweep", "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
                                "algorithmic_bytes_per_launch": alg / max(launches, 1),
                                "index_ms": index_ms, "commit_ms": commit_ms, "sweep_ms": sweep_ms,
-                               "note": "achieved = 588 B x view evaluations counted on the device / HIP-event time of k_sweep; the kernel is bound by VALU "
-                                       "issue (over 90 % of SIMD time, DESIGN.md section 5), and the 131 MB of pyramids sit in the Infinity Cache"}
+                               "index_ms_per_step": index_ms / max(args.steps, 1), "commit_ms_per_step": commit_ms / max(args.steps, 1),
+                               "note": "achieved = 588 B x view evaluations counted on the device / HIP-event time of k_sweep; the label is the contract's choice of "
+                                       "two: the kernel is bound by VALU issue (DESIGN.md section 5) and the 131 MB of pyramids sit in the Infinity Cache"}
             if ex is not None:
                 out["roofline"]["rank"] = 0
-                out["exchange"] = {"ms": exchange_ms, "bytes_gathered_per_rank": exchange_bytes, "collective": "all_gather_into_tensor (RCCL)",
-                                   "note": "counts + padded 128-byte patch records + kill ids, after each colour pass"}
+                out["exchange"] = {"ms": exchange_ms, "bytes_gathered_per_rank": exchange_bytes, "collective": exchange}
         if world == 1 and args.cpu_seconds > 0:
             log("cpu baseline ...")
-            out["cpu_baseline"] = cpu_baseline(args, sc, seeds)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(args, sc, seeds, pool_after_iter0, patches_by_iter if patches_by_iter[0] else [1, 0, 0])
+            out["cpu_baseline_all_cores"] = out["cpu_baseline"]["all_cores"]
+        print(json.dumps(out), flush=True)
     e.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -148,6 +148,22 @@ int mvs_engine_export_device(mvs_engine* e, void* d_new_records, int64_t cap_new
 int mvs_engine_commit_device(mvs_engine* e, const void* d_new_records, int64_t n_new, const void* d_kill_ids, int64_t n_kill);
 int mvs_engine_commit_local(mvs_engine* e);
 
+/* ---- multi-GPU through the C ABI (no reference counterpart: the reference is one thread on one CPU).
+ * One engine per process and GPU; every engine is created with shard_index = rank, shard_count = world, holds the whole
+ * pool and all pyramids, and sweeps its contiguous range of the (view, cell) job sequence.  The engines of a job share an
+ * RCCL communicator; after each colour pass mvs_engine_exchange all-gathers, on the engine's own stream, (1) the counts
+ * (one ncclAllGather of two int64 per rank), (2) the new 128-byte records, each rank's block broadcast straight into its
+ * final place behind the pool (ranges are contiguous, so rank order IS the global (view, cell, creation) order), and
+ * (3) the ids of evicted patches -- then commits the union, so all pools stay identical and equal to the 1-GPU result.
+ * With a communicator attached, mvs_engine_propagate does pass + exchange itself: PmMvps::run needs no other change.
+ * librccl is opened at run time (dlopen); without it these calls return MVS_ERR_STATE and everything else still works. */
+#define MVS_COMM_ID_BYTES 128
+int mvs_comm_unique_id(void* id_out /* MVS_COMM_ID_BYTES */); /* ncclGetUniqueId: rank 0 calls it and hands the bytes to the other ranks (file, socket, MPI ...) */
+int mvs_engine_comm_init(mvs_engine* e, const void* id /* MVS_COMM_ID_BYTES */, int rank, int world); /* ncclCommInitRank on the engine's device; collective */
+int mvs_engine_comm_attach(mvs_engine* e, void* nccl_comm /* ncclComm_t the host owns */, int rank, int world);
+int mvs_engine_comm_release(mvs_engine* e); /* destroys the communicator comm_init made / forgets an attached one */
+int mvs_engine_exchange(mvs_engine* e);     /* after mvs_engine_pass: all-gather + commit of the union; collective */
+
 /* parity artefact: kind 0 = m_dpgrids patch, kind 1 = best-NCC patch of
  * m_pgrids[view][cell] whose reference view is `view`.  depth[gw*gh] = oaxis.coord, normal[gw*gh*3],
  * ids[gw*gh]; empty cells are NaN / -1.  Host buffers. */
@@ -172,6 +188,8 @@ typedef struct mvs_timing {
     float sweep_ms;  /* the sweep kernel(s) */
     float commit_ms; /* commit */
     int32_t sweep_launches;
+    float exchange_ms;      /* mvs_engine_exchange: count all-gather + record / kill-id broadcasts (HIP events) */
+    int64_t exchange_bytes; /* bytes this rank received in them */
 } mvs_timing;
 int mvs_engine_last_timing(mvs_engine* e, mvs_timing* t);
 

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmvskit_engine.so")
 SOURCES = ["mvs_kernels.hip", "mvs_engine.cpp"]
-DEPS = SOURCES + ["mvs_device.cuh", "mvs_types.h", "mvs_kernels.h", os.path.join(ROOT, "include", "mvskit_engine.h")]
+DEPS = SOURCES + ["mvs_device.cuh", "mvs_check.cuh", "mvs_types.h", "mvs_kernels.h", os.path.join(ROOT, "include", "mvskit_engine.h")]
 
 # -ffp-contract=off: the explicit fmaf chains in the source are the only fused operations (DESIGN.md,
 # "engine arithmetic"), which is what lets the CPU oracle reproduce the results bit for bit.
@@ -37,7 +37,7 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + FLAGS + os.environ.get("MVS_EXTRA_FLAGS", "").split() + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

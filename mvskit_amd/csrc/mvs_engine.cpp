@@ -1,6 +1,8 @@
 // mvs_engine.cpp -- host side of the C ABI in include/mvskit_engine.h: device memory, camera set-up,
 // the per-pass schedule (index build -> sweep -> commit) on one HIP stream, HIP-event timing.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: librccl is opened at run time (see Rccl below)
 
 #include <algorithm>
 #include <climits>
@@ -44,6 +46,76 @@ template <typename T> struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
+
+// RCCL, opened at run time.  A process that has loaded torch already holds torch's own librccl: that copy is reused
+// (one RCCL per process); otherwise the ROCm installation's is opened.  Nothing here is needed on one GPU.
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    const char* paths[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+    for (const char* n : paths) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!r.h) return r;
+#define MVS_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, name))
+    MVS_SYM(GetUniqueId, "ncclGetUniqueId"); MVS_SYM(CommInitRank, "ncclCommInitRank"); MVS_SYM(CommDestroy, "ncclCommDestroy");
+    MVS_SYM(AllGather, "ncclAllGather"); MVS_SYM(Broadcast, "ncclBroadcast"); MVS_SYM(GroupStart, "ncclGroupStart");
+    MVS_SYM(GroupEnd, "ncclGroupEnd"); MVS_SYM(GetErrorString, "ncclGetErrorString");
+#undef MVS_SYM
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Broadcast && r.GroupStart && r.GroupEnd && r.GetErrorString;
+    return r;
+}
+#define NCCLCHK(expr)                                                                                      \
+    do {                                                                                                   \
+        ncclResult_t _r = (expr);                                                                          \
+        if (_r != ncclSuccess) {                                                                           \
+            g_err = std::string(#expr) + ": " + rccl().GetErrorString(_r);                                 \
+            return MVS_ERR_HIP;                                                                            \
+        }                                                                                                  \
+    } while (0)
+
+// roctx ranges (tracing) around upload / index build / colour-pass sweep / exchange / commit /
+// Filter::run stages; libroctx64 is opened at run time and the ranges cost nothing when no profiler listens.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+Roctx& roctx() {
+    static Roctx r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    void* h = nullptr;
+    const char* names[] = {"libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so.4"};
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return r;
+    r.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    r.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!r.push || !r.pop) { r.push = nullptr; r.pop = nullptr; }
+    return r;
+}
+struct Range {
+    bool on;
+    explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
 }  // namespace
 
 struct mvs_engine {
@@ -85,8 +157,14 @@ struct mvs_engine {
     DevBuf<float> tmp_f_in, tmp_f_out;
     DevBuf<int32_t> tmp_i;
     DevBuf<uint8_t> tmp_bytes;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     mvs_timing timing{};
+    // multi-GPU (mvs_engine_comm_*): one RCCL communicator over the engines of the job
+    ncclComm_t comm = nullptr;
+    bool comm_owned = false;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf<int64_t> comm_counts;   // [2] mine + [2 * world] gathered
+    DevBuf<int32_t> comm_kill_ids; // all ranks' kill ids
 };
 
 namespace {
@@ -374,6 +452,8 @@ int mvs_engine_destroy(mvs_engine* e) {
     if (!e) return MVS_OK;
     (void)hipSetDevice(e->cfg.device);
     (void)hipStreamSynchronize(e->stream);
+    (void)mvs_engine_comm_release(e);
+    e->comm_counts.release(); e->comm_kill_ids.release();
     free_views(e);
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
@@ -392,6 +472,7 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
     if (!e || !views || nviews != e->cfg.nviews) { g_err = "mvs_engine_set_views: nviews must equal the configured number of views"; return MVS_ERR_ARG; }
     HIPCHK(hipSetDevice(e->cfg.device));
     hipStream_t st = e->stream;
+    Range rg("mvs:set_views (upload + pyramids)");
     free_views(e);
     const int maxLevel = e->cfg.level + 3;
     e->hviews.assign(nviews, DView{});
@@ -513,6 +594,7 @@ int mvs_engine_upload_patches(mvs_engine* e, int64_t n, const mvs_patch* patches
     if (n < 0 || (n > 0 && !patches)) return MVS_ERR_ARG;
     if (e->staged) { g_err = "mvs_engine_upload_patches: a pass is waiting for its commit"; return MVS_ERR_STATE; }
     HIPCHK(hipSetDevice(e->cfg.device));
+    Range rg("mvs:upload_patches");
     // readPatches (patch_manager.cpp:450-463): m_fix = 0, m_tmp = score2, m_vimages cleared, empty m_images dropped
     std::vector<mvs_patch> recs;
     recs.reserve((size_t)n);
@@ -580,8 +662,12 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     hipStream_t st = e->stream;
     HIPCHK(hipEventRecord(e->ev[0], st));
     unsigned long long trimmed = 0;
-    if (int r = build_index(e, &trimmed)) return r;
+    {
+        Range rg("mvs:index");
+        if (int r = build_index(e, &trimmed)) return r;
+    }
     HIPCHK(hipEventRecord(e->ev[1], st));
+    Range rg_sweep(pass & 1 ? "mvs:sweep colour 1" : "mvs:sweep colour 0");
     // jobs: one per (swept view, row, half column) of the pass colour
     SweepArgs& a = e->sa;
     memset(&a, 0, sizeof a);
@@ -625,7 +711,7 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->timing.index_ms = ms;
     (void)hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->timing.sweep_ms = ms;
-    e->timing.commit_ms = 0.0f; e->timing.sweep_launches = 1;
+    e->timing.commit_ms = 0.0f; e->timing.sweep_launches = 1; e->timing.exchange_ms = 0.0f; e->timing.exchange_bytes = 0;
     e->staged = true; e->counted = false;
     if (out) {
         out->candidates = (int64_t)hc.candidates; out->prefiltered = (int64_t)hc.prefiltered; out->patches = (int64_t)hc.patches;
@@ -691,6 +777,7 @@ int mvs_engine_commit_local(mvs_engine* e) {
     if (!e || !e->staged) { g_err = "mvs_engine_commit_local: no pass to commit"; return MVS_ERR_STATE; }
     HIPCHK(hipSetDevice(e->cfg.device));
     hipStream_t st = e->stream;
+    Range rg("mvs:commit");
     HIPCHK(hipEventRecord(e->ev[2], st));
     if (int r = ensure_counts(e)) return r;
     if (e->pool_n + e->n_new > e->pool.cap) { g_err = "mvs_engine_commit_local: patch pool capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
@@ -706,6 +793,116 @@ int mvs_engine_commit_local(mvs_engine* e) {
     return MVS_OK;
 }
 
+// ---- multi-GPU: RCCL communicator + the per-pass exchange (include/mvskit_engine.h, "multi-GPU through the C ABI")
+int mvs_comm_unique_id(void* id_out) {
+    if (!id_out) return MVS_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == MVS_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    if (!rccl().ok) { g_err = "mvs_comm_unique_id: librccl could not be opened"; return MVS_ERR_STATE; }
+    ncclUniqueId id;
+    NCCLCHK(rccl().GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return MVS_OK;
+}
+static int comm_check(mvs_engine* e, int rank, int world, const char* who) {
+    if (!e || world < 1 || rank < 0 || rank >= world) { g_err = std::string(who) + ": bad rank / world"; return MVS_ERR_ARG; }
+    if (e->comm) { g_err = std::string(who) + ": a communicator is already attached"; return MVS_ERR_STATE; }
+    const int sc = e->cfg.shard_count > 1 ? e->cfg.shard_count : 1, si = e->cfg.shard_count > 1 ? e->cfg.shard_index : 0;
+    if (sc != world || si != rank || e->cfg.view_begin != 0 || e->cfg.view_stride != 1) {
+        g_err = std::string(who) + ": the engine must be created with shard_index = rank and shard_count = world (contiguous job ranges: rank order is the commit order)";
+        return MVS_ERR_ARG;
+    }
+    if (!rccl().ok) { g_err = std::string(who) + ": librccl could not be opened"; return MVS_ERR_STATE; }
+    return MVS_OK;
+}
+int mvs_engine_comm_init(mvs_engine* e, const void* id, int rank, int world) {
+    if (!id) return MVS_ERR_ARG;
+    if (int r = comm_check(e, rank, world, "mvs_engine_comm_init")) return r;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t c = nullptr;
+    NCCLCHK(rccl().CommInitRank(&c, world, uid, rank));
+    e->comm = c; e->comm_owned = true; e->comm_rank = rank; e->comm_world = world;
+    return MVS_OK;
+}
+int mvs_engine_comm_attach(mvs_engine* e, void* nccl_comm, int rank, int world) {
+    if (!nccl_comm) return MVS_ERR_ARG;
+    if (int r = comm_check(e, rank, world, "mvs_engine_comm_attach")) return r;
+    e->comm = (ncclComm_t)nccl_comm; e->comm_owned = false; e->comm_rank = rank; e->comm_world = world;
+    return MVS_OK;
+}
+int mvs_engine_comm_release(mvs_engine* e) {
+    if (!e) return MVS_ERR_ARG;
+    if (e->comm && e->comm_owned && rccl().ok) {
+        (void)hipSetDevice(e->cfg.device);
+        (void)hipStreamSynchronize(e->stream);
+        (void)rccl().CommDestroy(e->comm);
+    }
+    e->comm = nullptr; e->comm_owned = false; e->comm_rank = 0; e->comm_world = 1;
+    return MVS_OK;
+}
+
+int mvs_engine_exchange(mvs_engine* e) {
+    if (!e || !e->staged) { g_err = "mvs_engine_exchange: no pass to exchange"; return MVS_ERR_STATE; }
+    if (!e->comm) { g_err = "mvs_engine_exchange: no communicator (mvs_engine_comm_init / _attach)"; return MVS_ERR_STATE; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->stream;
+    const Rccl& R = rccl();
+    const int world = e->comm_world, rank = e->comm_rank;
+    Range rg("mvs:exchange");
+    HIPCHK(hipEventRecord(e->ev[4], st));
+    if (int r = ensure_counts(e)) return r;
+    // (1) counts: one all-gather of {n_new, n_kill} per rank
+    if (int r = e->comm_counts.ensure(2 + 2 * (int64_t)world)) return r;
+    const int64_t mine[2] = {e->n_new, e->n_kill};
+    std::vector<int64_t> all(2 * (size_t)world);
+    HIPCHK(hipMemcpyAsync(e->comm_counts.p, mine, sizeof mine, hipMemcpyHostToDevice, st));
+    NCCLCHK(R.AllGather(e->comm_counts.p, e->comm_counts.p + 2, 2, ncclInt64, e->comm, st));
+    HIPCHK(hipMemcpyAsync(all.data(), e->comm_counts.p + 2, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int64_t> off_new(world + 1, 0), off_kill(world + 1, 0);
+    for (int r = 0; r < world; ++r) { off_new[r + 1] = off_new[r] + all[2 * r]; off_kill[r + 1] = off_kill[r] + all[2 * r + 1]; }
+    const int64_t tot_new = off_new[world], tot_kill = off_kill[world];
+    if (all[2 * rank] != e->n_new || all[2 * rank + 1] != e->n_kill) { g_err = "mvs_engine_exchange: count all-gather returned other values for this rank"; return MVS_ERR_STATE; }
+    if (e->pool_n + tot_new > e->pool.cap) {  // every rank sees the same totals and fails alike
+        g_err = "mvs_engine_exchange: patch pool capacity exceeded (raise mvs_config.max_patches)";
+        return MVS_ERR_CAPACITY;
+    }
+    if (int r = e->comm_kill_ids.ensure(std::max<int64_t>(tot_kill, 16))) return r;
+    // (2) this rank's block goes straight to its final place behind the pool, (3) every block is broadcast in place.
+    // Job ranges are contiguous and ascending in rank, so the concatenation in rank order is the global
+    // (view, cell, creation) order of the 1-GPU commit.
+    DPatch* tail = e->pool.p + e->pool_n;
+    if (e->n_new > 0) mvsk_commit_copy(e->sa, e->job_base_scan.p, tail + off_new[rank], e->n_new, nullptr, 0, st);
+    if (e->n_kill > 0) mvsk_kill_export(e->kill.p, e->pool_n, e->kill_base.p, e->comm_kill_ids.p + off_kill[rank], e->n_kill, st);
+    NCCLCHK(R.GroupStart());
+    for (int r = 0; r < world; ++r) {
+        const int64_t nn = all[2 * r], nk = all[2 * r + 1];
+        if (nn > 0) NCCLCHK(R.Broadcast(tail + off_new[r], tail + off_new[r], (size_t)nn * sizeof(DPatch), ncclUint8, r, e->comm, st));
+        if (nk > 0) NCCLCHK(R.Broadcast(e->comm_kill_ids.p + off_kill[r], e->comm_kill_ids.p + off_kill[r], (size_t)nk, ncclInt32, r, e->comm, st));
+    }
+    NCCLCHK(R.GroupEnd());
+    HIPCHK(hipEventRecord(e->ev[5], st));
+    // commit of the union (the same on every rank)
+    {
+        Range rc("mvs:commit");
+        HIPCHK(hipEventRecord(e->ev[2], st));
+        mvsk_apply_kill_ids(e->pool.p, e->comm_kill_ids.p, tot_kill, e->pool_n, st);
+        if (e->pool_n > 0) HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));
+        e->pool_n += tot_new;
+        if (int r = compact_pool(e)) return r;
+        HIPCHK(hipEventRecord(e->ev[3], st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+    }
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e->ev[4], e->ev[5]); e->timing.exchange_ms = ms;
+    (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->timing.commit_ms = ms;
+    e->timing.exchange_bytes = (tot_new - e->n_new) * (int64_t)sizeof(DPatch) + (tot_kill - e->n_kill) * 4 + 16 * (int64_t)(world - 1);
+    e->staged = false; e->counted = false; e->index_valid = false;
+    return MVS_OK;
+}
+
 int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out) {  // Propagate::run, propagate.cpp:28-64
     mvs_counters total;
     memset(&total, 0, sizeof total);
@@ -714,9 +911,11 @@ int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out) {  // Propa
         mvs_counters c;
         memset(&c, 0, sizeof c);
         if (int r = mvs_engine_pass(e, iter, pass, &c)) return r;
-        if (int r = mvs_engine_commit_local(e)) return r;
+        if (e->comm) { if (int r = mvs_engine_exchange(e)) return r; }
+        else if (int r = mvs_engine_commit_local(e)) return r;
         add_counters(total, c);
         tt.index_ms += e->timing.index_ms; tt.sweep_ms += e->timing.sweep_ms; tt.commit_ms += e->timing.commit_ms; tt.sweep_launches += 1;
+        tt.exchange_ms += e->timing.exchange_ms; tt.exchange_bytes += e->timing.exchange_bytes;
     }
     e->timing = tt;
     if (out) *out = total;
@@ -729,6 +928,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     HIPCHK(hipSetDevice(e->cfg.device));
     hipStream_t st = e->stream;
     int64_t rem[4] = {0, 0, 0, 0};
+    Range rg("mvs:Filter::run");
     HIPCHK(hipEventRecord(e->ev[0], st));
     HIPCHK(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
     if (e->pool_n > 0) HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));

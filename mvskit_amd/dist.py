@@ -1,4 +1,12 @@
-"""View-sharded Propagate::run across the GPUs of one node.
+"""Sharded Propagate::run across the GPUs of one node.
+
+The product path is INSIDE the engine (include/mvskit_engine.h, "multi-GPU through the C ABI"): every rank creates its
+engine with shard_index = rank / shard_count = world, the ranks share an RCCL communicator (mvs_engine_comm_init) and
+mvs_engine_propagate exchanges and commits after each colour pass on the engine's own stream.  `EngineExchange` below
+only distributes the communicator id over torch.distributed.  The classes further down stage the exchange through the
+host instead: they serve the CPU tests (oracle-backed engines over gloo) and rehearsals in which several ranks share
+one GPU, which RCCL refuses.
+
 
 Every rank holds the whole patch pool and all image pyramids (98 MB for 12 x 1080p), sweeps the views
 `rank, rank + world, ...` (mvs_config.view_begin / view_stride) and, after each colour pass, exchanges what
@@ -90,62 +98,6 @@ def sharded_propagate_host(engine, iter_index: int, exchange: HostExchange, nvie
     return totals
 
 
-class DeviceExchange:
-    """Exchange through device tensors + torch.distributed backend "nccl" (= RCCL over xGMI on ROCm)."""
-
-    def __init__(self, device, group=None):
-        import torch
-        import torch.distributed as dist
-
-        self.torch, self.dist = torch, dist
-        self.group = group
-        self.device = device
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
-
-    def propagate(self, engine, iter_index: int):
-        """One Propagate::run(iter) on the rank's views; returns this rank's counters."""
-        torch, dist, world = self.torch, self.dist, self.world
-        import time
-
-        nviews = engine.cfg.nviews
-        totals = None
-        self.last_timing = {"index_ms": 0.0, "sweep_ms": 0.0, "commit_ms": 0.0, "sweep_launches": 0, "exchange_ms": 0.0, "exchange_bytes": 0}
-        for p in range(2):
-            c = engine.engine_pass(iter_index, p)
-            t = engine.timing()
-            for k in ("index_ms", "sweep_ms", "sweep_launches"):
-                self.last_timing[k] += t[k]
-            t_ex = time.perf_counter()
-            n_new, n_kill, per_view = engine.export_counts()
-            mine = torch.zeros(nviews + 2, dtype=torch.int64, device=self.device)
-            mine[:nviews] = torch.as_tensor(per_view.astype(np.int64), device=self.device)
-            mine[nviews], mine[nviews + 1] = n_new, n_kill
-            counts = torch.zeros(world, nviews + 2, dtype=torch.int64, device=self.device)
-            dist.all_gather_into_tensor(counts, mine, group=self.group)
-            counts_h = counts.cpu().numpy()
-            max_new, max_kill = int(counts_h[:, nviews].max()), int(counts_h[:, nviews + 1].max())
-            rec = torch.zeros(max(max_new, 1), RECORD_BYTES, dtype=torch.uint8, device=self.device)
-            kil = torch.full((max(max_kill, 1),), -1, dtype=torch.int32, device=self.device)
-            torch.cuda.synchronize(self.device)  # rec/kil were filled on torch's stream; the engine writes on its own
-            engine.export_device(rec.data_ptr(), rec.shape[0], kil.data_ptr(), kil.shape[0])
-            grec = torch.empty(world, rec.shape[0], RECORD_BYTES, dtype=torch.uint8, device=self.device)
-            gkil = torch.empty(world, kil.shape[0], dtype=torch.int32, device=self.device)
-            dist.all_gather_into_tensor(grec, rec, group=self.group)
-            dist.all_gather_into_tensor(gkil, kil, group=self.group)
-            parts = merge_in_view_order([grec[r] for r in range(world)], [counts_h[r, :nviews] for r in range(world)], nviews, world)
-            allrec = torch.cat(parts) if parts else torch.zeros(0, RECORD_BYTES, dtype=torch.uint8, device=self.device)
-            allkill = torch.cat([gkil[r, : int(counts_h[r, nviews + 1])] for r in range(world)]) if max_kill else torch.zeros(0, dtype=torch.int32, device=self.device)
-            allrec, allkill = allrec.contiguous(), allkill.contiguous()
-            torch.cuda.synchronize(self.device)  # the engine commits on its own HIP stream
-            self.last_timing["exchange_ms"] += 1000.0 * (time.perf_counter() - t_ex)
-            self.last_timing["exchange_bytes"] += int(grec.numel() + 4 * gkil.numel() + 8 * counts.numel())
-            engine.commit_device(allrec.data_ptr(), allrec.shape[0], allkill.data_ptr(), allkill.shape[0])
-            self.last_timing["commit_ms"] += engine.timing()["commit_ms"]
-            totals = c if totals is None else {k: totals[k] + c[k] for k in c}
-        return totals
-
-
 class HostStaged:
     """Adapter giving an `Engine` the host-side pass/export/commit interface `sharded_propagate_host` drives (the
     exchange then runs over any torch.distributed backend on CPU tensors, e.g. gloo when several ranks share one GPU)."""
@@ -177,3 +129,65 @@ class HostStaged:
         k = torch.from_numpy(np.ascontiguousarray(kills, dtype=np.int32).copy()).to(self.device)
         torch.cuda.synchronize(self.device)
         self.e.commit_device(r.data_ptr(), r.shape[0], k.data_ptr(), k.shape[0])
+
+
+class EngineExchange:
+    """The in-engine exchange: an RCCL communicator of the engine's own (created from an id that rank 0 generates and
+    torch.distributed broadcasts), all-gather + commit inside mvs_engine_propagate."""
+
+    def __init__(self, engine, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.e = engine
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = torch.zeros(engine.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).clone()
+        backend = dist.get_backend(group)
+        buf = uid.to(device) if backend == "nccl" else uid
+        dist.broadcast(buf, src=0, group=group)
+        engine.comm_init(bytes(buf.cpu().numpy().tobytes()), rank, world)
+        self.description = ("in-engine RCCL exchange on the engine's stream: ncclAllGather of the counts, then every rank's block of 128-byte patch records "
+                            "and kill ids broadcast in place behind the pool (grouped ncclBroadcast = all-gather-v)")
+        self.last_timing = {}
+
+    def propagate(self, iter_index: int):
+        c = self.e.propagate(iter_index)
+        self.last_timing = self.e.timing()
+        return c
+
+
+class HostStagedExchange:
+    """Rehearsal path for ranks that share one GPU (RCCL refuses two ranks on a device): pass / export to device buffers /
+    host copy / all-gather over gloo / commit_device.  Same call shape as EngineExchange."""
+
+    def __init__(self, engine, device, nviews, group=None):
+        from .synth import PATCH_DTYPE
+
+        self.e, self.nviews, self.dtype = engine, nviews, PATCH_DTYPE
+        self.staged = HostStaged(engine, device)
+        self.ex = HostExchange(group)
+        self.last_timing = {}
+
+    def propagate(self, iter_index: int):
+        import time
+
+        t = {"index_ms": 0.0, "sweep_ms": 0.0, "commit_ms": 0.0, "sweep_launches": 0, "exchange_ms": 0.0, "exchange_bytes": 0}
+        totals = None
+        for p in range(2):
+            c = self.staged.engine_pass(iter_index, p)
+            tt = self.e.timing()
+            for k in ("index_ms", "sweep_ms", "sweep_launches"):
+                t[k] += tt[k]
+            t0 = time.perf_counter()
+            new, per_view = self.staged.export_new()
+            kills = self.staged.export_kills()
+            allrec, allkill = self.ex.exchange(new, per_view, kills, self.nviews)
+            t["exchange_ms"] += 1000.0 * (time.perf_counter() - t0)
+            t["exchange_bytes"] += int(allrec.size + 4 * allkill.size)
+            self.staged.commit(allrec.view(self.dtype).reshape(-1), allkill)
+            t["commit_ms"] += self.e.timing()["commit_ms"]
+            totals = c if totals is None else {k: totals[k] + c[k] for k in c}
+        self.last_timing = t
+        return totals

@@ -21,7 +21,8 @@ EXPORTS = [
     "mvs_engine_clear_patches", "mvs_engine_num_patches", "mvs_engine_download_patches", "mvs_engine_propagate",
     "mvs_engine_pass", "mvs_engine_export_counts", "mvs_engine_export_device", "mvs_engine_commit_device",
     "mvs_engine_commit_local", "mvs_engine_depth_normal_map", "mvs_engine_probe", "mvs_engine_last_timing",
-    "mvs_engine_filter",
+    "mvs_engine_filter", "mvs_comm_unique_id", "mvs_engine_comm_init", "mvs_engine_comm_attach", "mvs_engine_comm_release",
+    "mvs_engine_exchange",
 ]
 
 
@@ -49,7 +50,8 @@ class Counters(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [("index_ms", C.c_float), ("sweep_ms", C.c_float), ("commit_ms", C.c_float), ("sweep_launches", C.c_int32)]
+    _fields_ = [("index_ms", C.c_float), ("sweep_ms", C.c_float), ("commit_ms", C.c_float), ("sweep_launches", C.c_int32),
+                ("exchange_ms", C.c_float), ("exchange_bytes", C.c_int64)]
 
 
 class EngineError(RuntimeError):
@@ -100,6 +102,11 @@ def load_library():
     L.mvs_engine_probe.argtypes = [vp, C.c_int, C.c_int64, vp, vp, vp, vp, vp]
     L.mvs_engine_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.mvs_engine_filter.argtypes = [vp, vp]
+    L.mvs_comm_unique_id.argtypes = [vp]
+    L.mvs_engine_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.mvs_engine_comm_attach.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.mvs_engine_comm_release.argtypes = [vp]
+    L.mvs_engine_exchange.argtypes = [vp]
     _lib = L
     return L
 
@@ -236,10 +243,30 @@ class Engine:
     def commit_local(self):
         self._check(self.L.mvs_engine_commit_local(self.h))
 
+    # ---- multi-GPU (RCCL communicator inside the engine)
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self):
+        """ncclGetUniqueId as bytes; rank 0 calls it and hands the bytes to the other ranks."""
+        buf = C.create_string_buffer(self.COMM_ID_BYTES)
+        self._check(self.L.mvs_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        assert len(uid) == self.COMM_ID_BYTES
+        self._check(self.L.mvs_engine_comm_init(self.h, C.c_char_p(uid), rank, world))
+
+    def comm_release(self):
+        self._check(self.L.mvs_engine_comm_release(self.h))
+
+    def exchange(self):
+        self._check(self.L.mvs_engine_exchange(self.h))
+
     def timing(self):
         t = Timing()
         self._check(self.L.mvs_engine_last_timing(self.h, C.byref(t)))
-        return {"index_ms": t.index_ms, "sweep_ms": t.sweep_ms, "commit_ms": t.commit_ms, "sweep_launches": t.sweep_launches}
+        return {"index_ms": t.index_ms, "sweep_ms": t.sweep_ms, "commit_ms": t.commit_ms, "sweep_launches": t.sweep_launches,
+                "exchange_ms": t.exchange_ms, "exchange_bytes": int(t.exchange_bytes)}
 
     def depth_normal_map(self, view, kind):
         gw, gh = self.grid_dims(view)

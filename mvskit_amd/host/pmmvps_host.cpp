@@ -2,11 +2,13 @@
 #include "pmmvps_host.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <thread>
 
 namespace mvshost {
 
@@ -24,10 +26,11 @@ Option::Option() {  // option.cpp:19-33
     m_quadThreshold = 2.5f;
 }
 
-int Option::init(const string prefix, const string option) {  // option.cpp:35-149
+void Option::init(const string prefix, const string option) {
+    m_status = -1;  // option.cpp:35-149
     m_prefix = prefix; m_option = option;
     ifstream ifstr((prefix + option).c_str());
-    if (!ifstr.is_open()) { cerr << "Cannot open option file: " << prefix + option << endl; return -1; }
+    if (!ifstr.is_open()) { cerr << "Cannot open option file: " << prefix + option << endl; return; }
     string name;
     while (ifstr >> name) {
         if (name[0] == '#') { string rest; std::getline(ifstr, rest); continue; }
@@ -53,14 +56,14 @@ int Option::init(const string prefix, const string option) {  // option.cpp:35-1
                 for (int i = first; i < last; ++i) m_images.push_back(i);
             } else if (0 < m_flag) {
                 for (int i = 0; i < m_flag; ++i) { int idx; ifstr >> idx; m_images.push_back(idx); }
-            } else { cerr << "flag is not valid: " << m_flag << endl; return -1; }
-        } else { cerr << "Unrecognizable option: " << name << endl; return -1; }
+            } else { cerr << "flag is not valid: " << m_flag << endl; return; }
+        } else { cerr << "Unrecognizable option: " << name << endl; return; }
     }
-    if (m_flag == -10) { cerr << "m_flag not specified: " << m_flag << endl; return -1; }
+    if (m_flag == -10) { cerr << "m_flag not specified: " << m_flag << endl; return; }
     if (m_nimages == 0) m_nimages = (int)m_images.size();
     for (int i = 0; i < (int)m_images.size(); ++i) m_dict[m_images[i]] = i;
     initVisdata();
-    return 0;
+    m_status = 0;
 }
 
 void Option::initVisdata() {  // option.cpp:151-170
@@ -127,6 +130,30 @@ int Photo::readPgmMask(const string mname) {
     return is ? 0 : -1;
 }
 
+// Image::readPBMImage, image.cpp:881-946: binary P4; a set bit is background (0), a clear bit foreground (255).  As in
+// the reference the bits are taken as ONE continuous stream of width*height bits (no padding at the end of a row, which
+// the PBM format would have when the width is not a multiple of 8) -- masks written by the reference's tool chain are laid
+// out that way.
+int Photo::readPbmMask(const string mname) {
+    ifstream is(mname.c_str(), std::ios::binary);
+    string magic;
+    if (!is.is_open() || !(is >> magic) || magic != "P4") return -1;
+    int w = 0, h = 0;
+    while (is >> std::ws && is.peek() == '#') { string l; std::getline(is, l); }
+    is >> w;
+    while (is >> std::ws && is.peek() == '#') { string l; std::getline(is, l); }
+    is >> h;
+    is.get();
+    if (!is || w != m_width || h != m_height) return -1;
+    const size_t n = (size_t)w * h;
+    vector<unsigned char> bytes((n + 7) / 8);
+    is.read((char*)bytes.data(), (std::streamsize)bytes.size());
+    if (!is) return -1;
+    m_mask.resize(n);
+    for (size_t i = 0; i < n; ++i) m_mask[i] = ((bytes[i >> 3] >> (7 - (i & 7))) & 1) ? 0 : 255;
+    return 0;
+}
+
 int PhotoSet::init(const vector<int>& images, const string prefix, const int nimages, const int nillums, const int, const int, const int) {
     m_images = images; m_nimages = nimages; m_nillums = nillums; m_prefix = prefix;  // photoSet.cpp:20-61
     for (int i = 0; i < m_nimages; ++i) m_dict[images[i]] = i;
@@ -138,7 +165,10 @@ int PhotoSet::init(const vector<int>& images, const string prefix, const int nim
         snprintf(cname, sizeof cname, "%stxt/%08d.txt", prefix.c_str(), i);
         if (m_photos[i].initCamera(cname) != 0) return -1;
         if (m_photos[i].readPpm(iname) != 0) { cerr << "Unsupported image format found (only binary PPM): " << iname << endl; return -1; }
-        (void)m_photos[i].readPgmMask(mname);
+        if (m_photos[i].readPgmMask(mname) != 0) {  // Image::alloc tries .pgm, then .pbm (image.cpp:143-147)
+            snprintf(mname, sizeof mname, "%smask/%08d.pbm", prefix.c_str(), i);
+            (void)m_photos[i].readPbmMask(mname);
+        }
     }
     return 0;
 }
@@ -332,27 +362,27 @@ void Propagate::init() {  // propagate.cpp:23-26
     MAX_NUM_OF_PROPAG = 2;
     MAX_NUM_OF_PATCHES = MAX_NUM_OF_PROPAG * m_pmmvps.m_csize * m_pmmvps.m_csize;
 }
-int Propagate::run(const int iter) {  // propagate.cpp:28-64: the drop-in boundary
+void Propagate::run(const int iter) {  // propagate.cpp:28-64: the drop-in boundary
     m_ecount = m_fcount0 = m_fcount1 = m_pcount = 0;
+    if (m_pmmvps.m_status != 0) return;
     int r = mvs_engine_set_thresholds(m_pmmvps.m_engine, m_pmmvps.m_nccThreshold, m_pmmvps.m_nccThresholdBefore, m_pmmvps.m_depth);
     if (r == 0) r = mvs_engine_propagate(m_pmmvps.m_engine, iter, &m_counters);
-    if (r != 0) { cerr << "Propagate::run: " << mvs_last_error() << endl; return r; }
+    if (r != 0) { cerr << "Propagate::run: " << mvs_last_error() << endl; m_pmmvps.m_status = r; return; }
     m_ecount = m_counters.patches; m_fcount0 = m_counters.fail0; m_fcount1 = m_counters.fail1;
     m_pcount = m_counters.inserted + m_counters.replaced;
     cerr << "total pass fail0 fail1 refinepatch: " << m_ecount << " " << m_pcount << " " << m_fcount0 << " " << m_fcount1 << " "
          << m_pcount + m_fcount1 << endl;
-    return 0;
 }
 
 // ------------------------------------------------------------------ Filter
-int Filter::run() {  // filter.cpp:25-49
+void Filter::run() {  // filter.cpp:25-49
     int64_t r4[4] = {0, 0, 0, 0};
+    if (m_pmmvps.m_status != 0) return;
     int r = mvs_engine_set_thresholds(m_pmmvps.m_engine, m_pmmvps.m_nccThreshold, m_pmmvps.m_nccThresholdBefore, m_pmmvps.m_depth);
     if (r == 0) r = mvs_engine_filter(m_pmmvps.m_engine, r4);
-    if (r != 0) { cerr << "Filter::run: " << mvs_last_error() << endl; return r; }
+    if (r != 0) { cerr << "Filter::run: " << mvs_last_error() << endl; m_pmmvps.m_status = r; return; }
     for (int k = 0; k < 4; ++k) m_removed[k] = r4[k];
     cerr << "FilterOutside/Exact/Neighbor/Groups removed: " << r4[0] << " " << r4[1] << " " << r4[2] << " " << r4[3] << endl;
-    return 0;
 }
 
 // ------------------------------------------------------------------ PmMvps
@@ -367,6 +397,8 @@ int PmMvps::createEngine(float maxAngle, float quad) {
     cfg.maxAngleThreshold = maxAngle; cfg.quadThreshold = quad;
     cfg.depth = 0; cfg.seed = m_seed; cfg.refine_steps = m_refineSteps; cfg.view_propagation = m_viewPropagation;
     cfg.enable_check = 1;  // Optim::check from m_depth >= 2 (optim.cpp:292)
+    cfg.device = m_device;
+    if (m_world > 1 || !m_commIdFile.empty()) { cfg.shard_index = m_rank; cfg.shard_count = m_world; }
     int r = mvs_engine_create(&cfg, &m_engine);
     if (r != 0) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
     vector<mvs_view_desc> views(m_nimages);
@@ -379,10 +411,40 @@ int PmMvps::createEngine(float maxAngle, float quad) {
     }
     r = mvs_engine_set_views(m_engine, m_nimages, views.data());
     if (r != 0) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
+    return joinRanks();
+}
+
+void PmMvps::setRanks(int rank, int world, const string& idFile, int device) {
+    m_rank = rank; m_world = world; m_commIdFile = idFile;
+    m_device = device >= 0 ? device : rank;
+}
+// The communicator id travels through a file: rank 0 writes it (temporary name + rename, so a reader never sees half of
+// it), the other ranks wait for the file.  ncclCommInitRank inside mvs_engine_comm_init is the rendezvous itself.
+int PmMvps::joinRanks() {
+    if (m_commIdFile.empty()) return 0;
+    unsigned char id[MVS_COMM_ID_BYTES];
+    if (m_rank == 0) {
+        if (int r = mvs_comm_unique_id(id)) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
+        const string tmp = m_commIdFile + ".tmp";
+        std::ofstream o(tmp.c_str(), std::ios::binary);
+        o.write(reinterpret_cast<const char*>(id), sizeof id);
+        o.close();
+        if (!o || std::rename(tmp.c_str(), m_commIdFile.c_str()) != 0) { cerr << "PmMvps::init: cannot write " << m_commIdFile << endl; return MVS_ERR_ARG; }
+    } else {
+        bool got = false;
+        for (int tries = 0; tries < 1200 && !got; ++tries) {  // up to two minutes
+            std::ifstream i(m_commIdFile.c_str(), std::ios::binary);
+            if (i.is_open() && i.read(reinterpret_cast<char*>(id), sizeof id) && i.gcount() == (std::streamsize)sizeof id) got = true;
+            else std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        }
+        if (!got) { cerr << "PmMvps::init: no communicator id in " << m_commIdFile << endl; return MVS_ERR_STATE; }
+    }
+    if (int r = mvs_engine_comm_init(m_engine, id, m_rank, m_world)) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
     return 0;
 }
 
-int PmMvps::init(const Option& option, const PhotoSet& photos) {  // pmmvps.cpp:18-68
+void PmMvps::init(const Option& option, const PhotoSet& photos) {  // pmmvps.cpp:18-68
+    m_status = 0;
     m_images = option.m_images; m_nimages = option.m_nimages; m_nillums = option.m_nillums;
     m_prefix = option.m_prefix; m_level = option.m_level; m_csize = option.m_csize;
     m_nccThreshold = option.m_nccThreshold; m_wsize = option.m_wsize; m_minImageNumThreshold = option.m_minImageNum;
@@ -397,32 +459,34 @@ int PmMvps::init(const Option& option, const PhotoSet& photos) {  // pmmvps.cpp:
     m_nccThresholdBefore = m_nccThreshold - 0.3f;
     m_maxAngleThreshold = option.m_maxAngleThreshold;
     m_quadThreshold = option.m_quadThreshold;
-    if (int r = createEngine(option.m_maxAngleThreshold, option.m_quadThreshold)) return r;
+    if (int r = createEngine(option.m_maxAngleThreshold, option.m_quadThreshold)) { m_status = r; return; }
     m_patchManager.init();
     m_propagate.init();
     m_filter.init();
-    return 0;
 }
-int PmMvps::init(const Option& option) {
+void PmMvps::init(const Option& option) {
     PhotoSet ps;
-    if (ps.init(option.m_images, option.m_prefix, option.m_nimages, option.m_nillums, option.m_level + 3, option.m_wsize, 1) != 0) return MVS_ERR_ARG;
-    return init(option, ps);
+    if (option.m_status != 0 ||
+        ps.init(option.m_images, option.m_prefix, option.m_nimages, option.m_nillums, option.m_level + 3, option.m_wsize, 1) != 0) { m_status = MVS_ERR_ARG; return; }
+    init(option, ps);
 }
 void PmMvps::updateThreshold() { m_nccThreshold -= 0.05f; m_nccThresholdBefore -= 0.05f; m_countThreshold1 = 2; }
 
-int PmMvps::run() {  // pmmvps.cpp:76-114
+void PmMvps::run() {  // pmmvps.cpp:76-114
+    if (m_status != 0) return;
     if (m_writeFiles) (void)m_patchManager.readPatches();  // DepthNormInit::createPatches, isTest branch (depth_normal_init.cpp:29-33)
     ++m_depth;
     for (int iter = 0; iter < ITER; ++iter) {
         cerr << "\n---------------------\nIteration: " << iter << "\n---------------------" << endl;
-        if (int r = m_propagate.run(iter)) return r;
+        m_propagate.run(iter);
+        if (m_status != 0) return;
         if (m_writeFiles) m_patchManager.writePatches(m_prefix + "ply/refined_patches_before_refine_" + std::to_string(iter), true, false, false);
-        if (int r = m_filter.run()) return r;  // pmmvps.cpp:101
+        m_filter.run();  // pmmvps.cpp:101
+        if (m_status != 0) return;
         updateThreshold();
         ++m_depth;
         if (m_writeFiles) m_patchManager.writePatches(m_prefix + "ply/refined_patches_" + std::to_string(iter), true, false, false);
     }
-    return 0;
 }
 
 }  // namespace mvshost
@@ -431,6 +495,13 @@ int PmMvps::run() {  // pmmvps.cpp:76-114
 static std::string g_ply_out;
 // the next mvshost_run also writes its final patches as a PLY file (PatchManager::writePly) to `path`; "" switches it off
 extern "C" void mvshost_set_ply_output(const char* path) { g_ply_out = path ? path : ""; }
+// the next mvshost_run is rank `rank` of `world` (PmMvps::setRanks); world = 0 switches it off again
+static struct { int rank = 0, world = 0, device = 0; std::string id_file; } g_ranks;
+static bool g_run_filter = true;
+extern "C" void mvshost_set_ranks(int rank, int world, const char* id_file, int device) {
+    g_ranks.rank = rank; g_ranks.world = world; g_ranks.device = device; g_ranks.id_file = id_file ? id_file : "";
+}
+extern "C" void mvshost_set_filter(int on) { g_run_filter = on != 0; }
 extern "C" int mvshost_run(int nviews, int width, int height, const float* P /*[n][12]*/, const unsigned char* rgb /*[n][H][W][3]*/,
                            int level, int csize, int wsize, int minImageNum, float nccThreshold, unsigned seed, int iters,
                            long long nseeds, const mvs_patch* seeds, long long cap, mvs_patch* out, long long* nout, long long* patches_total) {
@@ -447,14 +518,18 @@ extern "C" int mvshost_run(int nviews, int width, int height, const float* P /*[
     }
     PmMvps pmmvps;
     pmmvps.m_seed = seed; pmmvps.ITER = iters; pmmvps.m_writeFiles = false;
-    if (int r = pmmvps.init(option, ps)) return r;
+    if (g_ranks.world > 0) pmmvps.setRanks(g_ranks.rank, g_ranks.world, g_ranks.id_file, g_ranks.device);
+    pmmvps.init(option, ps);
+    if (pmmvps.m_status) return pmmvps.m_status;
     if (int r = mvs_engine_upload_patches(pmmvps.m_engine, nseeds, seeds)) return r;
     long long total = 0;
     ++pmmvps.m_depth;
     for (int iter = 0; iter < iters; ++iter) {
-        if (int r = pmmvps.m_propagate.run(iter)) return r;
+        pmmvps.m_propagate.run(iter);
+        if (pmmvps.m_status) return pmmvps.m_status;
         total += pmmvps.m_propagate.m_ecount;
-        if (int r = pmmvps.m_filter.run()) return r;
+        if (g_run_filter) pmmvps.m_filter.run();
+        if (pmmvps.m_status) return pmmvps.m_status;
         pmmvps.updateThreshold();
         ++pmmvps.m_depth;
     }
@@ -473,11 +548,13 @@ extern "C" int mvshost_run(int nviews, int width, int height, const float* P /*[
 extern "C" int mvshost_run_dataset(const char* prefix, int iters, unsigned seed, long long cap, mvs_patch* out, long long* nout) {
     using namespace mvshost;
     Option option;
-    if (option.init(prefix, "option") != 0) return MVS_ERR_ARG;
+    option.init(prefix, "option");
+    if (option.m_status != 0) return MVS_ERR_ARG;
     PmMvps pmmvps;
     pmmvps.m_seed = seed; pmmvps.ITER = iters; pmmvps.m_writeFiles = true;
-    if (int r = pmmvps.init(option)) return r;
-    if (int r = pmmvps.run()) return r;
+    pmmvps.init(option);
+    pmmvps.run();
+    if (pmmvps.m_status) return pmmvps.m_status;
     pmmvps.m_patchManager.collectPatches();
     const auto& pp = pmmvps.m_patchManager.m_ppatches;
     *nout = (long long)pp.size();
@@ -489,7 +566,8 @@ extern "C" int mvshost_run_dataset(const char* prefix, int iters, unsigned seed,
 // Option::init on a file: out_i = {nimages, level, csize, wsize, minImageNum, flag, #images}, out_f = {threshold, maxAngle, quad}
 extern "C" int mvshost_option_probe(const char* prefix, const char* option, int* out_i, float* out_f) {
     mvshost::Option o;
-    const int r = o.init(prefix, option);
+    o.init(prefix, option);
+    const int r = o.m_status;
     out_i[0] = o.m_nimages; out_i[1] = o.m_level; out_i[2] = o.m_csize; out_i[3] = o.m_wsize; out_i[4] = o.m_minImageNum;
     out_i[5] = o.m_flag; out_i[6] = (int)o.m_images.size();
     out_f[0] = o.m_nccThreshold; out_f[1] = o.m_maxAngleThreshold; out_f[2] = o.m_quadThreshold;
@@ -509,6 +587,13 @@ extern "C" int mvshost_patch_roundtrip(const char* text, char* out, int cap, mvs
     return (int)s.size();
 }
 // Camera text (camera.cpp:27-63): returns the 3x4 projection
+extern "C" int mvshost_pbm_probe(const char* mname, int width, int height, unsigned char* out) {
+    mvshost::Photo ph;
+    ph.m_width = width; ph.m_height = height;
+    if (ph.readPbmMask(mname) != 0) return -1;
+    memcpy(out, ph.m_mask.data(), ph.m_mask.size());
+    return 0;
+}
 extern "C" int mvshost_camera_probe(const char* cname, float* P12) {
     mvshost::Photo ph;
     const int r = ph.initCamera(cname);

@@ -27,8 +27,10 @@ typedef std::array<float, 4> Vector4f;
 // pmmvps/option.hpp:20-73
 struct Option {
     Option();
-    // returns 0, or -1 with a message on std::cerr (the reference exit(1)s, option.cpp:113-128)
-    int init(const string prefix, const string option);
+    // option.hpp:24.  Where the reference prints and exit(1)s (option.cpp:113-128) the message goes to std::cerr and
+    // m_status becomes -1: a library must not end the process of its caller.
+    void init(const string prefix, const string option);
+    int m_status = 0;
 
     int m_nimages, m_nillums, m_level, m_csize;
     float m_nccThreshold;
@@ -56,6 +58,7 @@ struct Photo {
     // binary PPM (P6) reader; PhotoSet::init accepts `image/%04d%04d.ppm` (photoSet.cpp:33-36)
     int readPpm(const string iname);
     int readPgmMask(const string mname);  // P5, thresholded at 127 (image.cpp:170-177)
+    int readPbmMask(const string mname);  // P4, Image::readPBMImage (image.cpp:881-946)
 };
 
 // image/photoSet.hpp:23-62
@@ -119,7 +122,7 @@ class Propagate {
 public:
     explicit Propagate(PmMvps& pmmvps) : m_pmmvps(pmmvps) {}
     void init();
-    int run(const int iter);
+    void run(const int iter);  // propagate.hpp:30; a failure is reported through PmMvps::m_status
     int MAX_NUM_OF_PATCHES = 0, MAX_NUM_OF_PROPAG = 0;
     long long m_ecount = 0, m_fcount0 = 0, m_fcount1 = 0, m_pcount = 0;
     mvs_counters m_counters{};
@@ -133,7 +136,7 @@ class Filter {
 public:
     explicit Filter(PmMvps& pmmvps) : m_pmmvps(pmmvps) {}
     void init() {}
-    int run();  // filter.cpp:25-49, on the engine
+    void run();  // filter.hpp / filter.cpp:25-49, on the engine; a failure is reported through PmMvps::m_status
     long long m_removed[4] = {0, 0, 0, 0};  // filterOutside / filterExact / filterNeighbor / filterSmallGroups
 
 protected:
@@ -145,11 +148,20 @@ class PmMvps {
 public:
     PmMvps();
     virtual ~PmMvps();
-    // returns 0 or a negative mvs_status (the reference exit(1)s)
-    int init(const Option& option);
-    int init(const Option& option, const PhotoSet& photos);  // photos already in memory
-    int run();
+    // pmmvps.hpp:30-31.  Where the reference exit(1)s, m_status becomes a negative mvs_status (0 = fine) and the call
+    // returns; later calls do nothing while m_status != 0.
+    void init(const Option& option);
+    void init(const Option& option, const PhotoSet& photos);  // photos already in memory
+    void run();
+    int m_status = 0;
     int ITER = 3;  // pmmvps.cpp:90 (compile-time constant there; D13)
+    // Multi-GPU (no reference counterpart): one PmMvps per process and GPU.  Call before init(): this process is rank
+    // `rank` of `world`; `idFile` is a path all ranks can reach -- rank 0 writes the RCCL communicator id there, the
+    // others wait for it (mvs_comm_unique_id / mvs_engine_comm_init).  Every rank then runs the same init()/run(): the
+    // engine sweeps its share of the cells and exchanges inside Propagate::run; all ranks end with the same patches.
+    void setRanks(int rank, int world, const string& idFile, int device = -1);
+    int m_rank = 0, m_world = 1, m_device = 0;
+    string m_commIdFile;
 
     int m_nimages = 0, m_nillums = 1;
     vector<int> m_images;
@@ -179,6 +191,7 @@ public:
 
 protected:
     int createEngine(float maxAngle, float quad);
+    int joinRanks();
 };
 
 }  // namespace mvshost

@@ -153,8 +153,55 @@ def _shade(points, basis, chunk=1 << 18):
     return out
 
 
+def _raycast_torch(P, C, W, H, objects, dev):
+    """_raycast on the GPU (float64, the same formulas): a 4K view takes milliseconds instead of seconds."""
+    import torch
+
+    f64 = dict(dtype=torch.float64, device=dev)
+    Minv = torch.as_tensor(np.linalg.inv(P[:, :3].astype(np.float64)), **f64)
+    v, u = torch.meshgrid(torch.arange(H, **f64), torch.arange(W, **f64), indexing="ij")
+    d = torch.stack([u, v, torch.ones_like(u)], dim=-1) @ Minv.T
+    o = torch.as_tensor(np.asarray(C, dtype=np.float64), **f64)
+    best = torch.full((H, W), float("inf"), **f64)
+    pts = torch.full((H, W, 3), float("nan"), **f64)
+    nrm = torch.full((H, W, 3), float("nan"), **f64)
+    for ob in objects:
+        if isinstance(ob, Plane):
+            n = torch.as_tensor(np.asarray(ob.n, dtype=np.float64), **f64)
+            denom = d @ n
+            t = (ob.d - o @ n) / denom
+            X = o + t[..., None] * d
+            ok = (t > 1e-6) & (t < best) & (denom < 0)
+            xmin, xmax, ymin, ymax = ob.bounds
+            ok &= (X[..., 0] >= xmin) & (X[..., 0] <= xmax) & (X[..., 1] >= ymin) & (X[..., 1] <= ymax)
+            best = torch.where(ok, t, best)
+            pts = torch.where(ok[..., None], X, pts)
+            nrm = torch.where(ok[..., None], n.expand_as(nrm), nrm)
+        else:
+            c = torch.as_tensor(np.asarray(ob.c, dtype=np.float64), **f64)
+            oc = o - c
+            a = (d * d).sum(-1)
+            b = 2.0 * (d @ oc)
+            cc = oc @ oc - ob.r ** 2
+            disc = b * b - 4 * a * cc
+            t = (-b - torch.sqrt(disc)) / (2 * a)
+            ok = (disc > 0) & (t > 1e-6) & (t < best)
+            X = o + t[..., None] * d
+            best = torch.where(ok, t, best)
+            pts = torch.where(ok[..., None], X, pts)
+            nrm = torch.where(ok[..., None], (X - c) / ob.r, nrm)
+    return pts.to(torch.float32).cpu().numpy(), nrm.to(torch.float32).cpu().numpy()
+
+
 def _raycast(P, C, W, H, objects):
     """Nearest hit of every pixel-centre ray.  Returns points [H,W,3], normals [H,W,3] (NaN = miss)."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            return _raycast_torch(P, C, W, H, objects, "cuda")
+    except ImportError:  # pragma: no cover
+        pass
     M = P[:, :3].astype(np.float64)
     Minv = np.linalg.inv(M)
     u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
@@ -195,9 +242,11 @@ def _raycast(P, C, W, H, objects):
 
 
 def make_scene(nviews=12, W=1920, H=1080, arc_deg=110.0, radius=4.0, kind="multi", keep_geometry=True, tex_seed=12345,
-               noise_sigma=2.0):
+               noise_sigma=2.0, geometry_views=None):
     """cfg2-style scene: `nviews` cameras on an arc looking at 3 textured planes + a sphere
-    (kind="multi") or one textured plane z = 0 (kind="plane")."""
+    (kind="multi") or one textured plane z = 0 (kind="plane").  geometry_views: keep the ground-truth points / normals
+    (needed by make_seeds for reference views and occlusion tests) only for these views -- the others hold NaN, which
+    make_seeds reads as "not visible there" (48 views of 4K would need 19 GB otherwise)."""
     P, C = make_cameras(nviews, W, H, arc_deg, radius)
     focal = 765.702941895 * W / 640.0
     basis = _texture_basis(radius / focal, seed=tex_seed)
@@ -213,8 +262,12 @@ def make_scene(nviews=12, W=1920, H=1080, arc_deg=110.0, radius=4.0, kind="multi
             img = np.clip(np.rint(img.astype(np.float64) + nz), 0, 255).astype(np.uint8)
         imgs[i] = img
         if keep_geometry:
-            pts_all[i] = pts
-            nrm_all[i] = nrm
+            if geometry_views is None or i in geometry_views:
+                pts_all[i] = pts
+                nrm_all[i] = nrm
+            else:
+                pts_all[i] = np.nan
+                nrm_all[i] = np.nan
     return Scene(W=W, H=H, P=P, images=imgs, centers=C, points=pts_all, normals=nrm_all,
                  meta={"kind": kind, "arc_deg": arc_deg, "radius": radius, "focal": focal})
 

@@ -112,3 +112,150 @@ def test_full_size_properties(full_scene):
         assert h.patches().tobytes() == p.tobytes()
         h.close()
     e.close()
+
+
+def _cells_in_ref_view(sc, seeds, csize=2):
+    """Cell (cx, cy) of every seed in its reference view: PatchManager::setGrids, patch_manager.cpp:241-250."""
+    ref = seeds["images"][:, 0].astype(np.int64)
+    P = sc.P.astype(np.float64)[ref]
+    X = seeds["coord"].astype(np.float64)
+    x = np.einsum("nij,nj->ni", P, X)
+    px, py = x[:, 0] / x[:, 2], x[:, 1] / x[:, 2]
+    return np.floor(px + 0.5).astype(np.int64) // csize, np.floor(py + 0.5).astype(np.int64) // csize
+
+
+def test_full_size_windowed_parity_vs_oracle(full_scene):
+    """BASELINE configs[1] geometry (12 x 1920x1080: 960x540 cells per view, 6.2 M cells, cell_base up to 5.7 M, rows of
+    1920 texels) against the CPU oracle -- affordable because the seeds are confined to one 64x64-cell window per view,
+    each at a different place of its grid, so only those neighbourhoods have work.  Two iterations of PmMvps::run's loop
+    (pmmvps.cpp:90-105; the second with Optim::check): every counter equal, lists equal, coordinates and both depth /
+    normal maps within the north-star tolerance.  This is the test that would catch a W = 1920 addressing, cell_base or
+    job-index error that the 384x216 parity scenes cannot see."""
+    import oracle_binding as ob
+
+    from test_gpu_parity import REL_TOL, _maps_close
+
+    sc, seeds = full_scene
+    cx, cy = _cells_in_ref_view(sc, seeds)
+    ref = seeds["images"][:, 0].astype(np.int64)
+    gw, gh = 960, 540
+    keep = np.zeros(seeds.shape[0], bool)
+    for v in range(sc.nviews):  # windows spread over the grid: columns 140 .. 760, rows 100 .. 380
+        wx = 140 + (v * 389) % 620
+        wy = 100 + (v * 97) % 280
+        keep |= (ref == v) & (cx >= wx) & (cx < wx + 64) & (cy >= wy) & (cy < wy + 64)
+    win = np.ascontiguousarray(seeds[keep])
+    assert win.shape[0] > 1500, win.shape
+    kw = dict(level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=31)
+    o = ob.Oracle(sc.nviews, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64, nthreads=16, **kw)
+    e = engine.Engine(sc.nviews, **kw)
+    o.set_scene(sc)
+    e.set_scene(sc)
+    assert e.grid_dims(11) == (gw, gh) == o.grid_dims(11)
+    o.add_patches(win)
+    e.upload_patches(win)
+    total = 0
+    for it in range(2):
+        co, ce = o.propagate(it), e.propagate(it)
+        for k in ("candidates", "prefiltered", "patches", "fail0", "fail1", "inserted", "replaced", "evals", "view_evals", "trimmed"):
+            assert co[k] == ce[k], (it, k, co, ce)
+        total += ce["patches"]
+        o.update_threshold()
+        e.update_threshold()
+    assert total > 10000, total
+    po, pe = o.patches(), e.patches()
+    assert po.shape == pe.shape and pe.shape[0] > win.shape[0]
+    np.testing.assert_array_equal(po["nimages"], pe["nimages"])
+    np.testing.assert_array_equal(po["images"], pe["images"])
+    np.testing.assert_array_equal(po["vimages"], pe["vimages"])
+    np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+    np.testing.assert_allclose(pe["normal"], po["normal"], rtol=0, atol=REL_TOL)
+    np.testing.assert_allclose(pe["ncc"], po["ncc"], rtol=REL_TOL, atol=1e-5)
+    assert (pe["coord"] == po["coord"]).all(axis=1).mean() > 0.99
+    tot, bad = _maps_close(o, e, sc.nviews)
+    assert tot > 5000 and bad == 0, (tot, bad)
+    o.close()
+    e.close()
+
+
+def test_full_size_filter_run_properties(full_scene):
+    """BASELINE configs[4] at its size: Filter::run (filter.cpp:25-49) on the pool two full-size iterations leave behind
+    (too large for the oracle; the stage-by-stage parity is tests/test_gpu_parity.py::test_filter_run_matches_oracle)."""
+    sc, seeds = full_scene
+    e, _ = _run_single(sc, seeds)
+    before = e.patches()
+    removed = e.filter()
+    after = e.patches()
+    nrem = sum(removed.values())
+    assert all(v >= 0 for v in removed.values()) and nrem > 0
+    assert before.shape[0] - nrem == after.shape[0] == e.num_patches()
+    assert after.shape[0] > 0.5 * before.shape[0]
+    # every survivor is a patch that existed before (same position and normal), in the same relative order
+    key = lambda p: np.ascontiguousarray(np.concatenate([p["coord"], p["normal"]], axis=1)).view(np.dtype((np.void, 32))).ravel()
+    kb, ka = key(before), key(after)
+    pos = {k.tobytes(): i for i, k in enumerate(kb)}
+    idx = np.array([pos.get(k.tobytes(), -1) for k in ka])
+    assert (idx >= 0).all() and np.all(np.diff(idx) > 0)
+    b = before[idx]
+    # filterExact only removes views from m_images (filter.cpp:165-203) and every survivor keeps minImageNum of them
+    sel = np.arange(16)[None, :]
+    ia = np.where(sel < after["nimages"][:, None], after["images"][:, :16], 255)
+    ib = np.where(sel < b["nimages"][:, None], b["images"][:, :16], 254)
+    assert np.all((ia[:, :, None] == ib[:, None, :]).any(axis=2) | (ia == 255))
+    assert after["nimages"].min() >= CFG["minImageNum"]
+    assert np.all(after["nvimages"] <= 16) and np.isfinite(after["coord"]).all()
+    # bit-reproducible
+    e2, _ = _run_single(sc, seeds)
+    removed2 = e2.filter()
+    assert removed2 == removed and e2.patches().tobytes() == after.tobytes()
+    # and the propagation goes on from the filtered pool (PmMvps::run's next iteration)
+    e.update_threshold()
+    c = e.propagate(2)
+    assert c["patches"] > 100000 and c["candidates"] == c["prefiltered"] + c["patches"]
+    e.close()
+    e2.close()
+
+
+def test_config4_48_views_4k_fits_one_gpu():
+    """BASELINE configs[3] geometry on ONE MI355X: 48 views of 3840x2160 (99.5 M cells) resident in HBM -- pyramids, index,
+    depth maps, staging and a pool capped with mvs_config.max_patches -- one Propagate::run; the result is well formed and
+    the memory the engine took is recorded (gpurun_out/config4_fit.json)."""
+    import json
+    import os
+
+    import torch
+
+    n, W, H = 48, 3840, 2160
+    gv = tuple(range(0, n, 4))  # ground-truth geometry (seeds, occlusion test) for every fourth view
+    sc = synth.make_scene(nviews=n, W=W, H=H, arc_deg=110.0, radius=4.0, kind="multi", geometry_views=gv)
+    seeds = synth.make_seeds(sc, level=0, csize=2, stride=8, seed=777, views=gv)
+    sc.points = None
+    sc.normals = None
+    assert seeds.shape[0] > 300000
+    free0, total_mem = torch.cuda.mem_get_info(0)
+    e = engine.Engine(n, max_patches=48_000_000, **CFG)
+    e.set_scene(sc)
+    assert e.grid_dims(47) == (1920, 1080)
+    e.upload_patches(seeds)
+    c = e.propagate(0)
+    free1, _ = torch.cuda.mem_get_info(0)
+    t = e.timing()
+    assert c["candidates"] == c["prefiltered"] + c["patches"]
+    assert c["patches"] == c["fail0"] + c["fail1"] + c["inserted"] + c["replaced"]
+    assert c["patches"] > 1_000_000 and c["inserted"] > 500_000
+    p = e.patches()
+    made = p[p["dscale"] > 0]
+    assert 500_000 < made.shape[0] <= c["inserted"] + c["replaced"]
+    assert made["nimages"].min() >= CFG["minImageNum"] and made["nimages"].max() <= 16
+    k = np.arange(16)[None, :] < made["nimages"][:, None]
+    assert np.all(made["images"][:, :16][k] < n)
+    assert np.isfinite(made["coord"]).all() and np.all(made["ncc"] <= 1.0 + 1e-6)
+    used = (free0 - free1) / 2 ** 30
+    assert used < 288.0
+    rec = {"views": n, "width": W, "height": H, "cells": 48 * 1920 * 1080, "seeds": int(seeds.shape[0]), "max_patches": 48_000_000,
+           "hbm_used_GiB_after_one_iteration": used, "hbm_total_GiB": total_mem / 2 ** 30, "patches": c["patches"], "view_evals": c["view_evals"],
+           "timing_ms": t, "pool_alive": int(p.shape[0])}
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "config4_fit.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    e.close()

@@ -203,45 +203,44 @@ def test_three_iterations_with_check(small_multi_scene):
     assert tot > 2000 and bad == 0
 
 
-def test_device_exchange_world1_equals_local_commit(small_multi_scene):
-    """mvskit_amd.dist.DeviceExchange (export to device buffers, RCCL all-gather, commit of the union) with one rank must
-    give exactly the pool that the in-engine commit gives."""
-    import os
-
-    import torch
-    import torch.distributed as dist
-
-    from mvskit_amd.dist import DeviceExchange
-
+def test_engine_rccl_exchange_world1_equals_local_commit(small_multi_scene):
+    """The in-engine multi-GPU path of the C ABI (mvs_comm_unique_id / mvs_engine_comm_init / mvs_engine_exchange inside
+    mvs_engine_propagate: RCCL count all-gather, in-place broadcast of the record and kill-id blocks behind the pool, commit
+    of the union) with a communicator of one rank must give exactly the pool the local commit gives, Optim::check included."""
     sc = small_multi_scene
     seeds = synth.make_seeds(sc, stride=4, seed=23)
     kw = dict(level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=5)
     a = engine.Engine(sc.nviews, **kw)
-    b = engine.Engine(sc.nviews, **kw)
+    b = engine.Engine(sc.nviews, shard_index=0, shard_count=1, **kw)
     for e in (a, b):
         e.set_scene(sc)
         e.upload_patches(seeds)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-        created = True
-    try:
-        ex = DeviceExchange(torch.device("cuda", 0))
-        for it in range(2):
-            ca = a.propagate(it)
-            cb = ex.propagate(b, it)
-            assert ca == cb, (it, ca, cb)
-            a.update_threshold()
-            b.update_threshold()
-        pa, pb = a.patches(), b.patches()
-        assert pa.shape == pb.shape
-        for f in ("coord", "normal", "ncc", "dscale", "ascale", "tmp", "nimages", "images", "nvimages", "vimages"):
-            np.testing.assert_array_equal(pa[f], pb[f], err_msg=f)
-    finally:
-        if created:
-            dist.destroy_process_group()
+    b.comm_init(b.comm_unique_id(), 0, 1)
+    moved = 0
+    for it in range(3):
+        ca = a.propagate(it)
+        cb = b.propagate(it)
+        assert ca == cb, (it, ca, cb)
+        t = b.timing()
+        assert t["exchange_ms"] > 0.0 and t["exchange_bytes"] == 0  # one rank: nothing comes from elsewhere
+        moved += cb["inserted"] + cb["replaced"]
+        a.update_threshold()
+        b.update_threshold()
+    assert moved > 1000
+    pa, pb = a.patches(), b.patches()
+    assert pa.shape == pb.shape
+    assert pa.tobytes() == pb.tobytes()
+    # pass / exchange can also be driven one colour pass at a time
+    c0 = b.engine_pass(3, 0)
+    b.exchange()
+    assert c0["patches"] > 0
+    b.comm_release()
+    with pytest.raises(engine.EngineError):
+        b.engine_pass(3, 1)
+        b.exchange()  # no communicator any more
+    b.commit_local()
+    a.close()
+    b.close()
 
 
 def _one_iteration_matches(sc, seeds, masks=None, **kw):

@@ -21,6 +21,11 @@ def host():
     L.mvshost_run_dataset.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.c_longlong, C.c_void_p, C.c_void_p]
     L.mvshost_set_ply_output.argtypes = [C.c_char_p]
     L.mvshost_set_ply_output.restype = None
+    L.mvshost_pbm_probe.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    L.mvshost_set_ranks.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.mvshost_set_ranks.restype = None
+    L.mvshost_set_filter.argtypes = [C.c_int]
+    L.mvshost_set_filter.restype = None
     L.mvshost_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint,
                               C.c_int, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
@@ -84,6 +89,59 @@ def test_camera_text(host, tmp_path):
     np.testing.assert_allclose(got.reshape(3, 4), exp, rtol=2e-5, atol=1e-4)
     (tmp_path / "bad.txt").write_text("CONTOUR9\n1 2 3\n")
     assert host.mvshost_camera_probe(str(tmp_path / "bad.txt").encode(), got.ctypes.data) == -1  # camera.cpp:45-48
+
+
+def test_pbm_mask(host, tmp_path):
+    """Image::readPBMImage (image.cpp:881-946): binary P4, set bit = background (0), clear bit = 255, the bits taken as one
+    continuous stream (the reference does not skip the row padding of the PBM format)."""
+    w, h = 13, 5  # not a multiple of 8: the continuous-stream reading shows
+    rng = np.random.RandomState(4)
+    bits = rng.randint(0, 2, size=w * h).astype(np.uint8)
+    packed = np.packbits(bits)  # most significant bit first, as image.cpp:929-941 walks them
+    f = tmp_path / "00000000.pbm"
+    f.write_bytes(b"P4\n# made by the test\n%d %d\n" % (w, h) + packed.tobytes())
+    out = np.zeros(w * h, np.uint8)
+    assert host.mvshost_pbm_probe(str(f).encode(), w, h, out.ctypes.data) == 0
+    np.testing.assert_array_equal(out, np.where(bits == 1, 0, 255).astype(np.uint8))
+    assert host.mvshost_pbm_probe(str(f).encode(), w + 1, h, out.ctypes.data) == -1  # size must match the image
+    g = tmp_path / "ascii.pbm"
+    g.write_bytes(b"P1\n2 2\n0 1 1 0\n")
+    assert host.mvshost_pbm_probe(str(g).encode(), 2, 2, out.ctypes.data) == -1  # "Only accept binary pbm format"
+
+
+@pytest.mark.gpu
+def test_pmmvps_run_with_ranks_world1(host, small_multi_scene, tmp_path):
+    """The C++ host mirror with PmMvps::setRanks: communicator id through a file, engine created as shard 0 of 1,
+    mvs_engine_comm_init, and Propagate::run exchanging inside the engine over RCCL -- the code path every rank of an
+    N-GPU job runs -- must return the patches of the plain single-GPU run.  (RCCL refuses two ranks on one device, so one
+    rank is what a one-GPU box can execute; the N-rank merge logic is covered by tests/test_dist_gloo.py and
+    tests/test_gpu_dist.py.)"""
+    sc = small_multi_scene
+    seeds = synth.make_seeds(sc, stride=4, seed=21)
+    iters = 3
+    cap = 400000
+    P = np.ascontiguousarray(sc.P, dtype=np.float32)
+    img = np.ascontiguousarray(sc.images)
+    sd = np.ascontiguousarray(seeds)
+
+    def run():
+        out = np.zeros(cap, dtype=engine.PATCH_DTYPE)
+        n, ptot = C.c_longlong(), C.c_longlong()
+        assert host.mvshost_run(sc.nviews, sc.W, sc.H, P.ctypes.data, img.ctypes.data, 0, 2, 7, 3, C.c_float(0.7), 9, iters, sd.shape[0], sd.ctypes.data,
+                                cap, out.ctypes.data, C.byref(n), C.byref(ptot)) == 0
+        return out[: n.value].copy(), ptot.value
+
+    plain, total_plain = run()
+    idf = tmp_path / "comm.id"
+    host.mvshost_set_ranks(0, 1, str(idf).encode(), 0)
+    try:
+        ranked, total_ranked = run()
+    finally:
+        host.mvshost_set_ranks(0, 0, b"", 0)
+    assert idf.exists() and idf.stat().st_size == 128
+    assert total_plain == total_ranked and total_plain > 5000
+    assert plain.shape == ranked.shape and plain.shape[0] > seeds.shape[0]
+    assert plain.tobytes() == ranked.tobytes()
 
 
 @pytest.mark.gpu
