@@ -59,7 +59,7 @@ typedef struct mvs_config {
     int32_t nviews;          /* Option::m_nimages */
     int32_t level;           /* Option::m_level */
     int32_t csize;           /* Option::m_csize */
-    int32_t wsize;           /* Option::m_wsize (<= 8: one wavefront lane per sample) */
+    int32_t wsize;           /* Option::m_wsize (<= 7: the window's samples are dealt over the lanes of one wavefront) */
     int32_t minImageNum;     /* Option::m_minImageNum */
     int32_t max_propag;      /* Propagate::MAX_NUM_OF_PROPAG, propagate.cpp:24 */
     float nccThreshold;      /* Option::m_nccThreshold */

@@ -20,7 +20,7 @@ namespace mvsdev {
 // 16 waves per CU.  The oracle picks the table size by the same rule (engine_neighbor_order).
 #define MVS_HASH_CAP 2048
 #define MVS_ROW_CAP 576
-#define MVS_SET_LDS_FLOATS(HCAP, RCAP) ((HCAP) > 4 * (RCAP) ? (HCAP) : 4 * (RCAP))
+#define MVS_SET_LDS_FLOATS(HCAP, RCAP) (((HCAP) > 4 * (RCAP) ? (HCAP) : 4 * (RCAP)) + 64)  // + 20 doubles of filterQuad's normal equations
 #define MVS_CHECK_LDS_FLOATS 2368
 static_assert(MVS_SET_LDS_FLOATS(MVS_HASH_CAP, MVS_ROW_CAP) <= MVS_CHECK_LDS_FLOATS, "neighbour search LDS");
 #define MVS_FILTER_HASH_CAP MVS_HASH_CAP   // Filter::filterNeighbor, first launch over all patches: the same limits
@@ -304,6 +304,22 @@ DEV double wave_sum_f64(double x) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
 }
 
+// the same butterfly, the sum left in lane 63 only (no v_readlane: the value stays in vector registers)
+DEV double wave_sum_f64_l63(double x) {
+    x = x + dpp_d<0xB1, 0xf>(x);
+    x = x + dpp_d<0x4E, 0xf>(x);
+    x = x + dpp_d<0x141, 0xf>(x);
+    x = x + dpp_d<0x140, 0xf>(x);
+    x = x + dpp_d<0x142, 0xa>(x);
+    x = x + dpp_d<0x143, 0xc>(x);
+    return x;
+}
+DEV double shfl_f64(double x, int src) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __shfl((int)(b & 0xffffffffll), src), hi = __shfl((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
 // Filter::filterQuad, filter.cpp:329-392.  nb = sorted ids in LDS (n of them); rows = LDS scratch of 3*n floats
 // (fx, fy, fz per neighbour).  The three sums over the neighbours (mean distance, normal equations, residual) are
 // lane-strided partial sums (lane l takes neighbours l, l+64, ...) followed by a wave butterfly.
@@ -332,51 +348,55 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
                 else acc[k++] += (double)a[i] * (double)a[j];
             }
     }
-    double M[5][6];
+    // The 20 sums go through LDS into lanes: lane 6 r + c holds M[r][c] (A^T A | A^T b, symmetric part mirrored), and the
+    // pivoted elimination of Filter::lls runs with one matrix element per lane -- the same operations in the same order as
+    // the oracle's solve5 (every element update is f = M[r][col] / M[col][col]; M[r][k] -= f * M[col][k]), but 2 VGPRs of
+    // matrix instead of 60 uniform registers.
+    double* sums = reinterpret_cast<double*>(rows + 3 * ((n + 1) & ~1));  // behind the rows, 8-byte aligned
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+        const double v = wave_sum_f64_l63(acc[k]);
+        if (wc.lane == 63) sums[k] = v;
+    }
+    __syncthreads();
+    const int lr = min(wc.lane / 6, 4), lc = wc.lane % 6;
+    double m;
     {
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-#pragma unroll
-            for (int j = i; j < 5; ++j) { const double v = wave_sum_f64(acc[k++]); M[i][j] = v; M[j][i] = v; }
-            M[i][5] = wave_sum_f64(acc[15 + i]);
-        }
+        const int i = min(lr, lc), j = max(lr, lc);
+        const int idx = lc == 5 ? 15 + lr : i * 5 - (i * (i - 1)) / 2 + (j - i);
+        m = sums[idx];
     }
     double x[5] = {0, 0, 0, 0, 0};
     bool solved = true;
 #pragma unroll
     for (int col = 0; col < 5; ++col) {
         int piv = col;
-        double best = fabs(M[col][col]);
+        double best = fabs(shfl_f64(m, col * 6 + col));
 #pragma unroll
         for (int r = col + 1; r < 5; ++r) {
-            const double av = fabs(M[r][col]);
+            const double av = fabs(shfl_f64(m, r * 6 + col));
             if (av > best) { best = av; piv = r; }
         }
-#pragma unroll
-        for (int r = col + 1; r < 5; ++r) {
-            if (piv == r) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { const double tmp = M[col][k]; M[col][k] = M[r][k]; M[r][k] = tmp; }
-            }
-        }
-        if (fabs(M[col][col]) < 1e-30) solved = false;
+        int src = wc.lane;
+        if (lr == col) src = piv * 6 + lc;
+        else if (lr == piv) src = col * 6 + lc;
+        m = shfl_f64(m, src);
+        const double pv = shfl_f64(m, col * 6 + col);
+        if (fabs(pv) < 1e-30) solved = false;
         if (solved) {
-#pragma unroll
-            for (int r = col + 1; r < 5; ++r) {
-                const double f = M[r][col] / M[col][col];
-#pragma unroll
-                for (int k = col; k < 6; ++k) M[r][k] -= f * M[col][k];
-            }
+            const double f = shfl_f64(m, lr * 6 + col) / pv;
+            const double pc = shfl_f64(m, col * 6 + lc);
+            if (lr > col && lc >= col) m -= f * pc;
         }
     }
     if (solved) {
 #pragma unroll
         for (int r = 4; r >= 0; --r) {
-            double a2 = M[r][5];
+            double a2 = shfl_f64(m, r * 6 + 5);
 #pragma unroll
-            for (int k = r + 1; k < 5; ++k) a2 -= M[r][k] * x[k];
-            x[r] = a2 / M[r][r];
+            for (int k = r + 1; k < 5; ++k) a2 -= shfl_f64(m, r * 6 + k) * x[k];
+            x[r] = a2 / shfl_f64(m, r * 6 + r);
         }
     }
     const float x0 = solved ? (float)x[0] : 0.0f, x1 = solved ? (float)x[1] : 0.0f, x2 = solved ? (float)x[2] : 0.0f,

@@ -362,6 +362,13 @@ struct WaveCtx {
     float fx, fy;       // this lane's sample column / row
     float fm;           // 1 on sample lanes, 0 elsewhere
     unsigned evals, view_evals;
+    // class lanes (eval_steps3): lane 16 g + c of rows g < 3 owns samples c, c + 16, c + 32 of proposal g; the few samples
+    // beyond the last full 16 ("extras", sample 48 of a 7x7 window) sit in row 3, lane 48 + 3 e + g
+    unsigned cs[3];     // per iteration j: fx | fy << 8 | valid << 16
+    int cg;             // the proposal this lane samples for
+    int cpull;          // ds_bpermute address (4 * lane) whose partial sums this lane adds to its own: the extras
+    float cpullm;       // 1 on lanes that pull from another lane, else 0
+    int cnl;            // iterations (0: the window does not fit the layout, wsize 8)
 #ifdef MVS_STAGE_TIMING
     unsigned long long st_acc[8];  // diagnostic build: phase times, kept in registers and flushed once by the kernel
     unsigned long long st_t;
@@ -410,7 +417,8 @@ DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int
 #ifndef MVS_FRAME_LDS
 #define MVS_FRAME_LDS 1
 #endif
-#define MVS_FRAME_LDS_BYTES (48 * 48)  // frame lanes 0..47, 12 dwords each; the start of the kernel's dynamic LDS
+#define MVS_PIVOT_LDS4 144                         // float4 index of the per-view pivot colours (refinePatch, class lanes)
+#define MVS_FRAME_LDS_BYTES (48 * 48 + 16 * 16)    // frame lanes 0..47, 12 dwords each, + 16 pivots; the start of the kernel's dynamic LDS
 extern __shared__ float4 mvs_dyn_lds4[];
 DEV void frames_publish(const WaveCtx& wc, const Frame& f, int nlanes) {
     __syncthreads();  // whatever used the region before (setRefImage textures, Optim::check rows) is done
@@ -458,6 +466,21 @@ DEV void tex_centre(const DParams& prm, const WaveCtx& wc, const Pending& p, flo
     d1 = fma_(-a1, wc.fm, g);
     d2 = fma_(-a2, wc.fm, b);
 }
+// the same, the channel means handed out as well (the pivots of refinePatch's class-lane evaluations)
+DEV void tex_centre_m(const DParams& prm, const WaveCtx& wc, const Pending& p, float& d0, float& d1, float& d2, float& a0, float& a1, float& a2) {
+    const Texel2 q0 = p.q0, q1 = p.q1;
+    const float dx1 = p.dx1, dx0 = 1.0f - dx1, dy1 = p.dy1, dy0 = wc.fm - dy1;
+    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+    float r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
+    float g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
+    float b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
+    a0 = r; a1 = g; a2 = b;
+    wave_sum3(a0, a1, a2);
+    a0 *= prm.inv_sz; a1 *= prm.inv_sz; a2 *= prm.inv_sz;
+    d0 = fma_(-a0, wc.fm, r);
+    d1 = fma_(-a1, wc.fm, g);
+    d2 = fma_(-a2, wc.fm, b);
+}
 DEV float ssd_sum(float d0, float d1, float d2) { return wave_sum(fma_(d2, d2, fma_(d1, d1, d0 * d0))); }
 // Optim::dot, optim.cpp:601-609, on centred textures, before the scale factors
 DEV float tex_dot_sum(float a0, float a1, float a2, float b0, float b1, float b2) {
@@ -476,9 +499,12 @@ DEV float inv_msd(const DParams& prm, float ssd) {
 // and in okm[g] the bit mask of views that were sampled.  One sqrt/division sequence serves all NP*n views.
 // NP*U independent sampling chains are kept in flight per step (U consecutive views of each proposal), and the
 // loads of the next step are issued before the current step is reduced.
-template <int NP, int U>
-DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[NP], float& incc_l) {
+// PIV (single proposal only): piv[0..2] receive, in view lane k, the channel means of view k (128 for a view that was
+// not sampled) -- the pivots of the class-lane evaluations that follow in refinePatch.
+template <int NP, int U, bool PIV = false>
+DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[NP], float& incc_l, float* piv = nullptr) {
     constexpr int NS = NP * U;
+    static_assert(!PIV || NP == 1, "pivots come from a single-proposal evaluation");
     float d0[NP][3];
     float ssd_l = 1.0f, dot_l = 0.0f;
     Pending pr[NP], pn[NS];
@@ -497,6 +523,11 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
         for (int u = 0; u < U; ++u) pn[g * U + u] = TEX_ISSUE(16 * g + min(1 + u, n - 1));
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
+        if (PIV) {
+            float a0, a1, a2;
+            tex_centre_m(prm, wc, pr[g], d0[g][0], d0[g][1], d0[g][2], a0, a1, a2);
+            if (wc.lane == 0) { piv[0] = pr[g].ok ? a0 : 128.0f; piv[1] = pr[g].ok ? a1 : 128.0f; piv[2] = pr[g].ok ? a2 : 128.0f; }
+        } else
         tex_centre(prm, wc, pr[g], d0[g][0], d0[g][1], d0[g][2]);
         const float s = ssd_sum(d0[g][0], d0[g][1], d0[g][2]);
         okv[g] |= (unsigned)pr[g].ok;
@@ -518,6 +549,12 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
             for (int u = 0; u < U; ++u) {
                 const int k = k0 + u;
                 float e0, e1, e2;
+                if (PIV) {
+                    float a0, a1, a2;
+                    tex_centre_m(prm, wc, p[g * U + u], e0, e1, e2, a0, a1, a2);
+                    const bool okk = p[g * U + u].ok != 0;
+                    if (k < n && wc.lane == k) { piv[0] = okk ? a0 : 128.0f; piv[1] = okk ? a1 : 128.0f; piv[2] = okk ? a2 : 128.0f; }
+                } else
                 tex_centre(prm, wc, p[g * U + u], e0, e1, e2);
                 float s = fma_(e2, e2, fma_(e1, e1, e0 * e0));                        // ssd_sum
                 float dt = fma_(d0[g][2], e2, fma_(d0[g][1], e1, d0[g][0] * e0));     // tex_dot_sum
@@ -543,6 +580,118 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
         inv0_l = g == 1 ? i1 : (g == 2 ? i2 : inv0_l);
     }
     incc_l = 1.0f - (dot_l * (inv0_l * inv_l)) * prm.inv_3sz;
+}
+
+// ------------------------------------------------------------------ class-lane evaluation (the three proposals of a refinement step)
+// Optim::getTex sampling + normalize + dot for proposals g = 0..2 against the views k < n, with a lane per (proposal,
+// sample class) instead of a lane per sample: lane 16 g + c walks its samples c, c + 16, c + 32 of EVERY view and keeps
+// running sums -- colour, colour^2 and colour x reference colour (the reference view's colours of its own samples stay in
+// registers) -- so no sum crosses lanes per sample.  Per view the five sums are finished by the four DPP steps of a
+// 16-lane row, once for all three proposals, and dropped into view lane 16 g + k; the per-view scalars (1/msd, INCC) then
+// come out of one vector sequence as in eval_core.  Per (proposal, view, sample) that is ~57 vector instructions instead
+// of 104, and a wave instruction covers 48-51 samples.
+// Arithmetic (mirrored by the oracle, tex_stats_class16): colours are taken relative to a per-view pivot p (the view's
+// mean colour in refinePatch's first evaluation), c' = blend - p;  S1 = sum c', S2 = sum |c'|^2, S01 = sum c' . c0';
+// mean m = S1 / n;  ssd = max(S2 - S1 . m, 0);  dot = S01 - S1 . m0;  INCC = 1 - dot (inv0 inv) / 3n.  The sums run
+// j-ascending inside a lane, the extras lane is added to lane 16 g + e, then the row tree pairs lanes 1, 2, 4, 8 apart.
+struct ClsPend { Texel2 q0, q1; float dx1, dy1; };
+DEV float cvt_ub0(unsigned x) { return (float)(x & 255u); }
+DEV float cvt_ub1(unsigned x) { return (float)((x >> 8) & 255u); }
+DEV float cvt_ub2(unsigned x) { return (float)((x >> 16) & 255u); }
+struct ClsFrame { float tlx, tly, dxx, dxy, dyx, dyy; int w; unsigned long long base; };
+DEV ClsFrame cls_frame(int fidx) {
+    const float4* s = mvs_dyn_lds4 + 3 * fidx;
+    const float4 A = s[0], B = s[1];
+    const float2 Cc = *reinterpret_cast<const float2*>(s + 2);
+    ClsFrame f;
+    f.tlx = A.x; f.tly = A.y; f.dxx = A.z; f.dxy = A.w; f.dyx = B.x; f.dyy = B.y; f.w = __float_as_int(B.z);
+    f.base = ((unsigned long long)(unsigned)__float_as_int(Cc.y) << 32) | (unsigned long long)(unsigned)__float_as_int(Cc.x);
+    return f;
+}
+DEV ClsPend cls_issue(const ClsFrame& f, unsigned cs) {
+    typedef const __attribute__((address_space(1))) uint32_t* GlobalTexels;
+    const float fx = cvt_ub0(cs), fy = cvt_ub1(cs);
+    const bool valid = (cs >> 16) != 0u;
+    const float sx = valid ? fma_(f.dyx, fy, fma_(f.dxx, fx, f.tlx)) : 0.0f;
+    const float sy = valid ? fma_(f.dyy, fy, fma_(f.dxy, fx, f.tly)) : 0.0f;
+    const int lx = (int)sx, ly = (int)sy;
+    const unsigned long long a0 = f.base + 4ull * (unsigned long long)(unsigned)(ly * f.w + lx);
+    const GlobalTexels t0 = (GlobalTexels)a0, t1 = (GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)f.w);
+    ClsPend p;
+    p.q0.a = t0[0]; p.q0.b = t0[1];
+    p.q1.a = t1[0]; p.q1.b = t1[1];
+    p.dx1 = sx - (float)lx; p.dy1 = sy - (float)ly;
+    return p;
+}
+// bilinear blend (Image::getColor, image.cpp:447-472) minus the pivot; 0 on lanes whose sample does not exist
+DEV void cls_colour(const ClsPend& p, unsigned cs, float pr, float pg, float pb, float& r, float& g, float& b) {
+    const Texel2 q0 = p.q0, q1 = p.q1;
+    const float fm = cvt_ub2(cs);
+    const float dx1 = p.dx1, dx0 = 1.0f - dx1, dy1 = p.dy1, dy0 = fm - dy1;
+    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+    r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
+    g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
+    b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
+    r = fma_(-pr, fm, r); g = fma_(-pg, fm, g); b = fma_(-pb, fm, b);
+}
+DEV float bperm_f(int addr, float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x))); }
+#define MVS_ROW_STEP5(C) { const float t0 = dpp_f<C>(s1r), t1 = dpp_f<C>(s1g), t2 = dpp_f<C>(s1b), t3 = dpp_f<C>(s2), t4 = dpp_f<C>(s01); \
+                           s1r = s1r + t0; s1g = s1g + t1; s1b = s1b + t2; s2 = s2 + t3; s01 = s01 + t4; }
+// frames: published in LDS for frame lanes 16 g + k (frames_publish); okm[g] = views of proposal g that sample.
+// Leaves in frame lane 16 g + k (k >= 1) the INCC of view k against the reference view of proposal g.
+DEV void eval_steps3(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[3], float& incc_l) {
+    frames_publish(wc, f, 48);
+    const unsigned long long okb = ballot(f.ok != 0);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) okm[g] = (unsigned)((okb >> (16 * g)) & 0xffffull);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) wc.view_evals += (okm[g] & 1u) ? (unsigned)__popc(okm[g]) : 0u;
+    const int fb = 16 * wc.cg;
+    const int nl = wc.cnl;
+    const int lc = wc.lane & 15;
+    float c0[3][3];
+    ClsPend pend[3];
+    float P1r = 0.0f, P1g = 0.0f, P1b = 0.0f, P2 = 0.0f, P01 = 0.0f;
+    {
+        const ClsFrame fr = cls_frame(fb);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if (j < nl) pend[j] = cls_issue(fr, wc.cs[j]);
+    }
+    for (int k = 0; k < n; ++k) {
+        const float4 pv = mvs_dyn_lds4[MVS_PIVOT_LDS4 + k];
+        const bool more = k + 1 < n;
+        ClsFrame fn;
+        if (more) fn = cls_frame(fb + k + 1);
+        float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f, s2 = 0.0f, s01 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < nl) {
+                float r, g, b;
+                cls_colour(pend[j], wc.cs[j], pv.x, pv.y, pv.z, r, g, b);
+                if (more) pend[j] = cls_issue(fn, wc.cs[j]);
+                if (k == 0) { c0[j][0] = r; c0[j][1] = g; c0[j][2] = b; }
+                s1r += r; s1g += g; s1b += b;
+                s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
+                s01 = fma_(r, c0[j][0], s01); s01 = fma_(g, c0[j][1], s01); s01 = fma_(b, c0[j][2], s01);
+            }
+        }
+        // the extras lane's sums join lane 16 g + e, then the row tree (lanes 1, 2, 4, 8 apart)
+        s1r = fma_(bperm_f(wc.cpull, s1r), wc.cpullm, s1r);
+        s1g = fma_(bperm_f(wc.cpull, s1g), wc.cpullm, s1g);
+        s1b = fma_(bperm_f(wc.cpull, s1b), wc.cpullm, s1b);
+        s2 = fma_(bperm_f(wc.cpull, s2), wc.cpullm, s2);
+        s01 = fma_(bperm_f(wc.cpull, s01), wc.cpullm, s01);
+        MVS_ROW_STEP5(0xB1) MVS_ROW_STEP5(0x4E) MVS_ROW_STEP5(0x141) MVS_ROW_STEP5(0x140)
+        if (lc == k) { P1r = s1r; P1g = s1g; P1b = s1b; P2 = s2; P01 = s01; }
+    }
+    // view lane 16 g + k: mean, ssd, centred product of view k; the reference view's mean and 1/msd come from lane 16 g
+    const float m_r = P1r * prm.inv_sz, m_g = P1g * prm.inv_sz, m_b = P1b * prm.inv_sz;
+    const float ssd = fmaxf(P2 - fma_(P1b, m_b, fma_(P1g, m_g, P1r * m_r)), 0.0f);
+    const float inv_l = inv_msd(prm, ssd);
+    const int a0 = (wc.lane & 48) << 2;
+    const float m0r = bperm_f(a0, m_r), m0g = bperm_f(a0, m_g), m0b = bperm_f(a0, m_b), inv0 = bperm_f(a0, inv_l);
+    const float dot = P01 - fma_(P1b, m0b, fma_(P1g, m0g, P1r * m0r));
+    incc_l = 1.0f - (dot * (inv0 * inv_l)) * prm.inv_3sz;
 }
 
 // ------------------------------------------------------------------ candidate patch (registers)
@@ -844,7 +993,7 @@ DEV double cost_of_group(const DParams& prm, const WaveCtx& wc, unsigned okm, fl
     return ans / (double)denom;
 }
 DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int imgx, int n, bool three, float x0, float x1, float x2,
-                    double& f0, double& f1, double& f2) {
+                    double& f0, double& f1, double& f2, float* piv = nullptr) {
     F4 coord, normal, px, py;
     decode(prm, rc, x0, x1, x2, coord, normal);
     get_paxes(prm, prm.views + rc.ref, coord, normal, px, py);
@@ -857,7 +1006,7 @@ DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
     if (three) {
         wc.evals += 3;
         unsigned okm[3];
-        eval_core<3, 1>(prm, wc, f, sz, okm, incc_l);
+        eval_steps3(prm, wc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
         // the three means: one fp64 division for all of them (lane j divides the sums of proposal j)
         double a0, a1, a2;
@@ -874,7 +1023,8 @@ DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
     } else {
         wc.evals += 1;
         unsigned okm[1];
-        eval_core<1, MVS_U1>(prm, wc, f, sz, okm, incc_l);
+        if (piv) eval_core<1, MVS_U1, true>(prm, wc, f, sz, okm, incc_l, piv);  // refinePatch's first evaluation: the view means become the pivots
+        else eval_core<1, MVS_U1>(prm, wc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
         f0 = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
     }
@@ -897,7 +1047,11 @@ STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, u
     x[2] = fmaxf(fminf(x[2], amax), amin);
     float bx0 = x[0], bx1 = x[1], bx2 = x[2];
     double f0, f1, f2;
-    cost_func3(prm, wc, rc, imgx, c.nimg, false, bx0, bx1, bx2, f0, f1, f2);
+    float piv[3] = {128.0f, 128.0f, 128.0f};  // view lanes: the mean colour of view k at the starting point
+    cost_func3(prm, wc, rc, imgx, c.nimg, false, bx0, bx1, bx2, f0, f1, f2, piv);
+    __syncthreads();
+    if (wc.lane < 16) mvs_dyn_lds4[MVS_PIVOT_LDS4 + wc.lane] = make_float4(piv[0], piv[1], piv[2], 0.0f);
+    __syncthreads();
     double fbest = f0;
     float rd = prm.rd0, ra = prm.ra0;
     const int g = wc.lane >> 4;  // this lane's proposal: 0 depth only, 1 angles only, 2 both (3: idle, computes proposal 2 again)
@@ -1139,6 +1293,23 @@ DEV WaveCtx make_wave_ctx(const DParams& prm) {
     wc.fx = (float)(wc.lane % prm.wsize);
     wc.fy = (float)(wc.lane / prm.wsize);
     wc.evals = 0; wc.view_evals = 0;
+    {   // class lanes: which samples this lane walks in eval_steps3
+        const int wsz = prm.wsz, nj = wsz >> 4, rem = wsz & 15;
+        const int rx = rem <= 5 ? rem : 0, njx = nj + (rem > 5 ? 1 : 0);
+        const int row = wc.lane >> 4, c = wc.lane & 15, t = wc.lane - 48;
+        wc.cg = row < 3 ? row : t % 3;
+        const int e = t / 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int s = row < 3 ? c + 16 * j : 16 * nj + e;
+            const bool valid = row < 3 ? (j < njx && s < (rem > 5 ? wsz : 16 * nj)) : (j == 0 && e < rx);
+            wc.cs[j] = valid ? (unsigned)(s % prm.wsize) | ((unsigned)(s / prm.wsize) << 8) | (1u << 16) : 0u;
+        }
+        const bool pulls = row < 3 && c < rx;
+        wc.cpull = 4 * (pulls ? 48 + 3 * c + row : wc.lane);
+        wc.cpullm = pulls ? 1.0f : 0.0f;
+        wc.cnl = max(njx, rx ? 1 : 0);
+    }
 #ifdef MVS_STAGE_TIMING
     for (int k = 0; k < 8; ++k) wc.st_acc[k] = 0;
     wc.st_t = 0;

@@ -425,10 +425,10 @@ void mvs_default_config(mvs_config* c) {  // Option::Option, option.cpp:19-33
 int mvs_engine_create(const mvs_config* cfg, mvs_engine** out) {
     if (!cfg || !out) { g_err = "mvs_engine_create: null argument"; return MVS_ERR_ARG; }
     if (cfg->shard_count > 1 && (cfg->shard_index < 0 || cfg->shard_index >= cfg->shard_count)) { g_err = "mvs_engine_create: bad shard_index"; return MVS_ERR_ARG; }
-    if (cfg->nviews < 1 || cfg->nviews > MVS_MAXVIEWS || cfg->wsize < 1 || cfg->wsize > 8 || cfg->csize < 1 || cfg->level < 0 ||
+    if (cfg->nviews < 1 || cfg->nviews > MVS_MAXVIEWS || cfg->wsize < 1 || cfg->wsize > 7 || cfg->csize < 1 || cfg->level < 0 ||
         cfg->level > 4 || cfg->max_propag < 1 || cfg->max_propag > 16 || cfg->max_propag * cfg->csize * cfg->csize > MVS_CAPMAX ||
         cfg->view_stride < 1 || cfg->view_begin < 0 || cfg->minImageNum < 1) {
-        g_err = "mvs_engine_create: configuration out of range (nviews <= 64, wsize <= 8, max_propag*csize^2 <= 32)";
+        g_err = "mvs_engine_create: configuration out of range (nviews <= 64, wsize <= 7, max_propag*csize^2 <= 32)";
         return MVS_ERR_ARG;
     }
     int ndev = 0;

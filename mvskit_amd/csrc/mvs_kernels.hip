@@ -793,7 +793,7 @@ __global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, co
 }
 
 // refinePatch alone (occupancy experiment / kernel benchmark): same arithmetic as probe op 2
-__global__ __launch_bounds__(64) void k_probe_refine(DParams prm, int64_t n, const DPatch* __restrict__ in, DPatch* __restrict__ out) {
+__global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_probe_refine(DParams prm, int64_t n, const DPatch* __restrict__ in, DPatch* __restrict__ out) {
     const int64_t i = blockIdx.x;
     if (i >= n) return;
     WaveCtx wc = make_wave_ctx(prm);

@@ -183,6 +183,7 @@ struct Patch { /* patch.hpp:23-67 */
 struct Tex { /* one grabbed 7x7 texture: channel-major, 64 lanes, lanes >= n are zero */
     float c[3][64];
     float inv; /* 1 / msd after normalize_tex; the samples stay centred, the scale is applied in dot_tex */
+    float ave[3]; /* channel means found by normalize_tex (the pivots of the class-lane evaluations, see tex_stats_class16) */
     bool ok;
 };
 
@@ -494,7 +495,7 @@ int get_tex(const Scene& s, const V4& coord, const V4& px, const V4& py, const V
 void normalize_tex(const Scene& s, Tex& tex) {
     const int sz = s.cfg.wsize * s.cfg.wsize;
     float ave[3];
-    for (int c = 0; c < 3; ++c) ave[c] = reduce(s, tex.c[c], sz) * s.inv_sz;
+    for (int c = 0; c < 3; ++c) { ave[c] = reduce(s, tex.c[c], sz) * s.inv_sz; tex.ave[c] = ave[c]; }
     float sq[64];
     for (int i = 0; i < 64; ++i) sq[i] = 0.0f;
     for (int i = 0; i < sz; ++i) {
@@ -816,7 +817,10 @@ void decode(const Scene& s, const RefineCtx& rc, const float* x, V4& coord, V4& 
 }
 
 /* Optim::cost_func, optim.cpp:401-468 (pairwise == 0 branch) */
-double cost_func(const Scene& s, const RefineCtx& rc, const int* idx, int n, const float* x, orc_counters* cnt) {
+/* piv != nullptr (engine arithmetic, the first evaluation of refinePatch): piv[i] receives the mean colour of view i at this
+ * point (128 for a view that was not sampled) -- the pivots of the class-lane evaluations of the refinement steps.  The
+ * engine samples every view of the list even when the reference view fails, so the means are taken the same way here. */
+double cost_func(const Scene& s, const RefineCtx& rc, const int* idx, int n, const float* x, orc_counters* cnt, float (*piv)[3] = nullptr) {
     V4 coord, normal, px, py;
     decode(s, rc, x, coord, normal);
     get_paxes(s, idx[0], coord, normal, px, py);
@@ -825,6 +829,15 @@ double cost_func(const Scene& s, const RefineCtx& rc, const int* idx, int n, con
     if (cnt) cnt->evals++;
     Tex t0, ti;
     if (get_tex(s, coord, px, py, normal, idx[0], t0, cnt) == 0) normalize_tex(s, t0);
+    if (piv) {
+        for (int c = 0; c < 3; ++c) piv[0][c] = t0.ok ? t0.ave[c] : 128.0f;
+        for (int i = 1; i < sz; ++i) {
+            Tex tp;
+            const bool okp = get_tex(s, coord, px, py, normal, idx[i], tp, nullptr) == 0;
+            if (okp) normalize_tex(s, tp);
+            for (int c = 0; c < 3; ++c) piv[i][c] = okp ? tp.ave[c] : 128.0f;
+        }
+    }
     if (!t0.ok) return 2.0;
     double ans = 0.0;
     int denom = 0;
@@ -832,6 +845,107 @@ double cost_func(const Scene& s, const RefineCtx& rc, const int* idx, int n, con
         if (get_tex(s, coord, px, py, normal, idx[i], ti, cnt) == 0) normalize_tex(s, ti);
         if (!ti.ok) continue;
         ans += robustincc((float)(1.0 - dot_tex(s, t0, ti)));
+        denom++;
+    }
+    if (denom < minimum - 1) return 2.0;
+    return ans / denom;
+}
+
+/* ---- class-lane arithmetic of the engine's refinement steps (mvs_device.cuh, eval_steps3) --------------------------------
+ * The 7x7 samples of one (proposal, view) are dealt over 16 lanes: lane c walks samples c, c + 16, c + 32 (as far as they
+ * exist) and the few samples beyond the last full 16 ("extras": sample 48 of a 7x7 window) sit in a lane of their own,
+ * whose sums are added to lane e.  Colours are taken relative to a pivot p per view, c' = colour - p, and normalize /
+ * dot (optim.cpp:917-940, 601-609) are computed from running sums instead of a centred copy of the texture:
+ *     S1 = sum c',  S2 = sum |c'|^2,  S01 = sum c' . c0'   (c0' = the reference view's colour of the same sample)
+ *     mean m = S1 / n,  ssd = max(S2 - S1 . m, 0),  dot = S01 - S1 . m0,  INCC = 1 - dot (inv0 inv) / 3n
+ * -- the same quantities (sum (c - mean)^2 = sum c^2 - n mean^2), the pivot keeping the squares small enough for fp32. */
+struct ClsLayout { int nj, rem, rx, njx, nl; };
+inline ClsLayout cls_layout(const Scene& s) {
+    ClsLayout L;
+    const int wsz = s.cfg.wsize * s.cfg.wsize;
+    L.nj = wsz >> 4; L.rem = wsz & 15;
+    L.rx = L.rem <= 5 ? L.rem : 0;
+    L.njx = L.nj + (L.rem > 5 ? 1 : 0);
+    L.nl = std::max(L.njx, L.rx ? 1 : 0);
+    return L;
+}
+inline float reduce_tree16(const float* a) { /* one DPP row: partners 1, 2, 4, 8 apart */
+    float b[16], t[16];
+    for (int i = 0; i < 16; ++i) b[i] = a[i];
+    for (int off = 1; off < 16; off <<= 1) {
+        for (int i = 0; i < 16; ++i) t[i] = b[i] + b[i ^ off];
+        for (int i = 0; i < 16; ++i) b[i] = t[i];
+    }
+    return b[0];
+}
+struct ClsSums { float s1[3], s2, s01; };
+/* tex: raw colours of one view; piv: its pivot; c0p: the reference view's c' per sample (nullptr for the reference view
+ * itself); cp_out: this view's c' per sample */
+void tex_stats_class16(const Scene& s, const Tex& tex, const float* piv, const float (*c0p)[64], float (*cp_out)[64], ClsSums& out) {
+    const ClsLayout L = cls_layout(s);
+    const int wsz = s.cfg.wsize * s.cfg.wsize;
+    float cp[3][64];
+    for (int i = 0; i < wsz; ++i) for (int c = 0; c < 3; ++c) cp[c][i] = fma_(-piv[c], 1.0f, tex.c[c][i]);
+    float l1[3][16], l2[16], l01[16];
+    const int lim = L.rem > 5 ? wsz : 16 * L.nj;
+    for (int c = 0; c < 16; ++c) {
+        float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f, s2 = 0.0f, s01 = 0.0f;
+        for (int j = 0; j < L.njx; ++j) {
+            const int q = c + 16 * j;
+            if (q >= lim) continue;
+            const float r = cp[0][q], g = cp[1][q], b = cp[2][q];
+            s1r += r; s1g += g; s1b += b;
+            s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
+            if (c0p) { s01 = fma_(r, c0p[0][q], s01); s01 = fma_(g, c0p[1][q], s01); s01 = fma_(b, c0p[2][q], s01); }
+        }
+        if (c < L.rx) { /* the extras lane: its own sums from zero, then added to this lane's */
+            const int q = 16 * L.nj + c;
+            const float r = cp[0][q], g = cp[1][q], b = cp[2][q];
+            float x1r = 0.0f, x1g = 0.0f, x1b = 0.0f, x2 = 0.0f, x01 = 0.0f;
+            x1r += r; x1g += g; x1b += b;
+            x2 = fma_(r, r, x2); x2 = fma_(g, g, x2); x2 = fma_(b, b, x2);
+            if (c0p) { x01 = fma_(r, c0p[0][q], x01); x01 = fma_(g, c0p[1][q], x01); x01 = fma_(b, c0p[2][q], x01); }
+            s1r = fma_(x1r, 1.0f, s1r); s1g = fma_(x1g, 1.0f, s1g); s1b = fma_(x1b, 1.0f, s1b);
+            s2 = fma_(x2, 1.0f, s2); s01 = fma_(x01, 1.0f, s01);
+        }
+        l1[0][c] = s1r; l1[1][c] = s1g; l1[2][c] = s1b; l2[c] = s2; l01[c] = s01;
+    }
+    for (int c = 0; c < 3; ++c) out.s1[c] = reduce_tree16(l1[c]);
+    out.s2 = reduce_tree16(l2);
+    out.s01 = reduce_tree16(l01);
+    if (cp_out) for (int c = 0; c < 3; ++c) for (int i = 0; i < 64; ++i) cp_out[c][i] = i < wsz ? cp[c][i] : 0.0f;
+}
+inline float cls_inv_msd(const Scene& s, const ClsSums& q, float* mean3) {
+    for (int c = 0; c < 3; ++c) mean3[c] = q.s1[c] * s.inv_sz;
+    const float ssd = std::max(q.s2 - fma_(q.s1[2], mean3[2], fma_(q.s1[1], mean3[1], q.s1[0] * mean3[0])), 0.0f);
+    float msd = sqrtf(ssd * s.inv_3sz);
+    if (msd == 0.0f) msd = 1.0f;
+    return 1.0f / msd;
+}
+/* Optim::cost_func (optim.cpp:401-468) in the class-lane arithmetic */
+double cost_func_cls(const Scene& s, const RefineCtx& rc, const int* idx, int n, const float* x, const float (*piv)[3], orc_counters* cnt) {
+    V4 coord, normal, px, py;
+    decode(s, rc, x, coord, normal);
+    get_paxes(s, idx[0], coord, normal, px, py);
+    const int sz = std::min(s.tau, n);
+    const int minimum = std::min(s.cfg.minImageNum, sz);
+    if (cnt) cnt->evals++;
+    Tex t0, ti;
+    if (get_tex(s, coord, px, py, normal, idx[0], t0, cnt) != 0) return 2.0;
+    float c0p[3][64];
+    ClsSums q0, qi;
+    tex_stats_class16(s, t0, piv[0], nullptr, c0p, q0);
+    float m0[3], mi[3];
+    const float inv0 = cls_inv_msd(s, q0, m0);
+    double ans = 0.0;
+    int denom = 0;
+    for (int i = 1; i < sz; ++i) {
+        if (get_tex(s, coord, px, py, normal, idx[i], ti, cnt) != 0) continue;
+        tex_stats_class16(s, ti, piv[i], c0p, nullptr, qi);
+        const float inv = cls_inv_msd(s, qi, mi);
+        const float dot = qi.s01 - fma_(qi.s1[2], m0[2], fma_(qi.s1[1], m0[1], qi.s1[0] * m0[0]));
+        const float incc = 1.0f - (dot * (inv0 * inv)) * s.inv_3sz;
+        ans += robustincc(incc);
         denom++;
     }
     if (denom < minimum - 1) return 2.0;
@@ -859,7 +973,13 @@ int refine_patch(const Scene& s, Patch& p, const uint32_t key[4], orc_counters* 
     const float amin = -23.99999f, amax = 23.99999f;
     x[1] = std::max(std::min(x[1], amax), amin);
     x[2] = std::max(std::min(x[2], amax), amin);
-    double fbest = cost_func(s, rc, p.img, p.nimg, x, cnt);
+    /* engine arithmetic: the three proposals of a step are evaluated in the class-lane layout, relative to the view means
+     * of this first evaluation; the reference's summation order (ORC_SUM_SEQ) keeps normalize / dot as they are */
+    const ClsLayout L = cls_layout(s);
+    const bool cls = s.cfg.sum_mode == ORC_SUM_TREE64 && L.nl >= 1 && L.njx <= 3;
+    float piv[MAXI][3];
+    for (int i = 0; i < MAXI; ++i) piv[i][0] = piv[i][1] = piv[i][2] = 128.0f;
+    double fbest = cost_func(s, rc, p.img, p.nimg, x, cnt, cls ? piv : nullptr);
     float rd = s.cfg.refine_rd0, ra = s.cfg.refine_ra0;
     for (int k = 0; k < s.cfg.refine_steps; ++k) {
         float cand[3][3];
@@ -872,7 +992,7 @@ int refine_patch(const Scene& s, Patch& p, const uint32_t key[4], orc_counters* 
             cand[j][0] = (j == 1) ? x[0] : fma_(u0, rd, x[0]);
             cand[j][1] = (j == 0) ? x[1] : std::max(std::min(fma_(u1, ra, x[1]), amax), amin);
             cand[j][2] = (j == 0) ? x[2] : std::max(std::min(fma_(u2, ra, x[2]), amax), amin);
-            f[j] = cost_func(s, rc, p.img, p.nimg, cand[j], cnt);
+            f[j] = cls ? cost_func_cls(s, rc, p.img, p.nimg, cand[j], piv, cnt) : cost_func(s, rc, p.img, p.nimg, cand[j], cnt);
         }
         int jb = 0;
         for (int j = 1; j < 3; ++j) if (f[j] < f[jb]) jb = j;
