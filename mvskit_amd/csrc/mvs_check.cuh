@@ -420,9 +420,17 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
     return residual < prm.quadThreshold ? 0 : 1;
 }
 
+#ifndef MVS_CHECK_OUTLINE
+#define MVS_CHECK_OUTLINE 0
+#endif
+#if MVS_CHECK_OUTLINE
+#define MVS_CHECK_FN __device__ __noinline__
+#else
+#define MVS_CHECK_FN DEV
+#endif
 // Optim::check, optim.cpp:300-323.  lds: MVS_CHECK_LDS_FLOATS floats (the kernel's dynamic LDS region).
 // Returns 1 when the patch is rejected.  Neighbours beyond MVS_ROW_CAP are ignored (and flagged in *overflow).
-DEV int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, Cand& c, float* lds, int* overflow) {
+MVS_CHECK_FN int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, Cand& c, float* lds, int* overflow) {
 #ifndef MVS_CHECK_STAGES
 #define MVS_CHECK_STAGES 3  // timing experiments only: 1 = gain, 2 = + neighbours, 3 = everything
 #endif

@@ -362,13 +362,6 @@ struct WaveCtx {
     float fx, fy;       // this lane's sample column / row
     float fm;           // 1 on sample lanes, 0 elsewhere
     unsigned evals, view_evals;
-    // class lanes (eval_steps3): lane 16 g + c of rows g < 3 owns samples c, c + 16, c + 32 of proposal g; the few samples
-    // beyond the last full 16 ("extras", sample 48 of a 7x7 window) sit in row 3, lane 48 + 3 e + g
-    unsigned cs[3];     // per iteration j: fx | fy << 8 | valid << 16
-    int cg;             // the proposal this lane samples for
-    int cpull;          // ds_bpermute address (4 * lane) whose partial sums this lane adds to its own: the extras
-    float cpullm;       // 1 on lanes that pull from another lane, else 0
-    int cnl;            // iterations (0: the window does not fit the layout, wsize 8)
 #ifdef MVS_STAGE_TIMING
     unsigned long long st_acc[8];  // diagnostic build: phase times, kept in registers and flushed once by the kernel
     unsigned long long st_t;
@@ -595,9 +588,38 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
 // mean m = S1 / n;  ssd = max(S2 - S1 . m, 0);  dot = S01 - S1 . m0;  INCC = 1 - dot (inv0 inv) / 3n.  The sums run
 // j-ascending inside a lane, the extras lane is added to lane 16 g + e, then the row tree pairs lanes 1, 2, 4, 8 apart.
 struct ClsPend { Texel2 q0, q1; float dx1, dy1; };
+// Per-lane constants of the class-lane layout: lane 16 g + c of rows g < 3 owns samples c, c + 16, c + 32 of proposal g;
+// the few samples beyond the last full 16 ("extras", sample 48 of a 7x7 window) sit in row 3, lane 48 + 3 e + g.
+struct ClsConst {
+    unsigned cs[3];  // per iteration j: fx | fy << 8 | valid << 16
+    int fb;          // first frame lane of this lane's proposal (16 g)
+    int pull;        // ds_bpermute address (4 * lane) of the extras lane whose sums this lane adds to its own
+    float pullm;     // 1 on lanes that pull, else 0
+};
+DEV ClsConst make_cls(const DParams& prm, const WaveCtx& wc) {
+    ClsConst cc;
+    const int wsz = prm.wsz, nj = wsz >> 4, rem = wsz & 15;
+    const int rx = rem <= 5 ? rem : 0, njx = nj + (rem > 5 ? 1 : 0);
+    const int row = wc.lane >> 4, c = wc.lane & 15, t = wc.lane - 48;
+    cc.fb = 16 * (row < 3 ? row : t % 3);
+    const int e = t / 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int s = row < 3 ? c + 16 * j : 16 * nj + e;
+        const bool valid = row < 3 ? (j < njx && s < (rem > 5 ? wsz : 16 * nj)) : (j == 0 && e < rx);
+        cc.cs[j] = valid ? (unsigned)(s % prm.wsize) | ((unsigned)(s / prm.wsize) << 8) | (1u << 16) : 0u;
+    }
+    const bool pulls = row < 3 && c < rx;
+    cc.pull = 4 * (pulls ? 48 + 3 * c + row : wc.lane);
+    cc.pullm = pulls ? 1.0f : 0.0f;
+    return cc;
+}
 DEV float cvt_ub0(unsigned x) { return (float)(x & 255u); }
 DEV float cvt_ub1(unsigned x) { return (float)((x >> 8) & 255u); }
 DEV float cvt_ub2(unsigned x) { return (float)((x >> 16) & 255u); }
+// The sample constants are unpacked where they are used (three v_cvt_f32_ubyte): hoisted out of the refinement loop as nine
+// floats they only turn into scratch traffic.  The empty asm hides the loop invariance from the optimiser.
+DEV unsigned cls_opaque(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 struct ClsFrame { float tlx, tly, dxx, dxy, dyx, dyy; int w; unsigned long long base; };
 DEV ClsFrame cls_frame(int fidx) {
     const float4* s = mvs_dyn_lds4 + 3 * fidx;
@@ -610,24 +632,26 @@ DEV ClsFrame cls_frame(int fidx) {
 }
 DEV ClsPend cls_issue(const ClsFrame& f, unsigned cs) {
     typedef const __attribute__((address_space(1))) uint32_t* GlobalTexels;
+    // a slot without a sample has cs = 0: it reads the window's first texels (a valid address) and is weighted out in
+    // cls_colour, so no select is needed here
     const float fx = cvt_ub0(cs), fy = cvt_ub1(cs);
-    const bool valid = (cs >> 16) != 0u;
-    const float sx = valid ? fma_(f.dyx, fy, fma_(f.dxx, fx, f.tlx)) : 0.0f;
-    const float sy = valid ? fma_(f.dyy, fy, fma_(f.dxy, fx, f.tly)) : 0.0f;
+    const float sx = fma_(f.dyx, fy, fma_(f.dxx, fx, f.tlx));
+    const float sy = fma_(f.dyy, fy, fma_(f.dxy, fx, f.tly));
     const int lx = (int)sx, ly = (int)sy;
     const unsigned long long a0 = f.base + 4ull * (unsigned long long)(unsigned)(ly * f.w + lx);
     const GlobalTexels t0 = (GlobalTexels)a0, t1 = (GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)f.w);
     ClsPend p;
     p.q0.a = t0[0]; p.q0.b = t0[1];
     p.q1.a = t1[0]; p.q1.b = t1[1];
-    p.dx1 = sx - (float)lx; p.dy1 = sy - (float)ly;
+    // sx - (float)(int)sx for the non-negative positions getTexSafe lets through: one v_fract_f32 (exact)
+    p.dx1 = __builtin_amdgcn_fractf(sx); p.dy1 = __builtin_amdgcn_fractf(sy);
     return p;
 }
 // bilinear blend (Image::getColor, image.cpp:447-472) minus the pivot; 0 on lanes whose sample does not exist
 DEV void cls_colour(const ClsPend& p, unsigned cs, float pr, float pg, float pb, float& r, float& g, float& b) {
     const Texel2 q0 = p.q0, q1 = p.q1;
-    const float fm = cvt_ub2(cs);
-    const float dx1 = p.dx1, dx0 = 1.0f - dx1, dy1 = p.dy1, dy0 = fm - dy1;
+    const float fm = cvt_ub2(cs);  // 1, or 0 for a slot without a sample: both column weights vanish, and with them all four
+    const float dx1 = p.dx1 * fm, dx0 = fm - dx1, dy1 = p.dy1, dy0 = 1.0f - dy1;
     const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
     r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
     g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
@@ -635,52 +659,73 @@ DEV void cls_colour(const ClsPend& p, unsigned cs, float pr, float pg, float pb,
     r = fma_(-pr, fm, r); g = fma_(-pg, fm, g); b = fma_(-pb, fm, b);
 }
 DEV float bperm_f(int addr, float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x))); }
+#define MVS_ROW_STEP(x, C) x = x + dpp_f<C>(x);
 #define MVS_ROW_STEP5(C) { const float t0 = dpp_f<C>(s1r), t1 = dpp_f<C>(s1g), t2 = dpp_f<C>(s1b), t3 = dpp_f<C>(s2), t4 = dpp_f<C>(s01); \
                            s1r = s1r + t0; s1g = s1g + t1; s1b = s1b + t2; s2 = s2 + t3; s01 = s01 + t4; }
+#define MVS_ROW_STEP4(C) { const float t0 = dpp_f<C>(s1r), t1 = dpp_f<C>(s1g), t2 = dpp_f<C>(s1b), t3 = dpp_f<C>(s2); \
+                           s1r = s1r + t0; s1g = s1g + t1; s1b = s1b + t2; s2 = s2 + t3; }
 // frames: published in LDS for frame lanes 16 g + k (frames_publish); okm[g] = views of proposal g that sample.
 // Leaves in frame lane 16 g + k (k >= 1) the INCC of view k against the reference view of proposal g.
-DEV void eval_steps3(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[3], float& incc_l) {
+// Straight-line per view (always three sample slots per lane; a slot without a sample contributes exact zeros), the
+// reference view peeled off, and the loads of view k + 1 issued as the slots of view k are consumed.
+DEV void eval_steps3(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const Frame& f, int n, unsigned (&okm)[3], float& incc_l) {
     frames_publish(wc, f, 48);
     const unsigned long long okb = ballot(f.ok != 0);
 #pragma unroll
     for (int g = 0; g < 3; ++g) okm[g] = (unsigned)((okb >> (16 * g)) & 0xffffull);
 #pragma unroll
     for (int g = 0; g < 3; ++g) wc.view_evals += (okm[g] & 1u) ? (unsigned)__popc(okm[g]) : 0u;
-    const int fb = 16 * wc.cg;
-    const int nl = wc.cnl;
+    const int fb = cc.fb;
     const int lc = wc.lane & 15;
     float c0[3][3];
     ClsPend pend[3];
-    float P1r = 0.0f, P1g = 0.0f, P1b = 0.0f, P2 = 0.0f, P01 = 0.0f;
+    float P1r, P1g, P1b, P2, P01 = 0.0f;
     {
         const ClsFrame fr = cls_frame(fb);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) if (j < nl) pend[j] = cls_issue(fr, wc.cs[j]);
+        for (int j = 0; j < 3; ++j) pend[j] = cls_issue(fr, cls_opaque(cc.cs[j]));
     }
-    for (int k = 0; k < n; ++k) {
+    {   // the reference view
+        const float4 pv = mvs_dyn_lds4[MVS_PIVOT_LDS4];
+        const ClsFrame fn = cls_frame(fb + min(1, n - 1));
+        float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned cs = cls_opaque(cc.cs[j]);
+            float r, g, b;
+            cls_colour(pend[j], cs, pv.x, pv.y, pv.z, r, g, b);
+            pend[j] = cls_issue(fn, cs);
+            c0[j][0] = r; c0[j][1] = g; c0[j][2] = b;
+            s1r += r; s1g += g; s1b += b;
+            s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
+        }
+        s1r = fma_(bperm_f(cc.pull, s1r), cc.pullm, s1r);
+        s1g = fma_(bperm_f(cc.pull, s1g), cc.pullm, s1g);
+        s1b = fma_(bperm_f(cc.pull, s1b), cc.pullm, s1b);
+        s2 = fma_(bperm_f(cc.pull, s2), cc.pullm, s2);
+        MVS_ROW_STEP4(0xB1) MVS_ROW_STEP4(0x4E) MVS_ROW_STEP4(0x141) MVS_ROW_STEP4(0x140)
+        P1r = s1r; P1g = s1g; P1b = s1b; P2 = s2;  // lanes lc != 0 are overwritten below or unused
+    }
+    for (int k = 1; k < n; ++k) {
         const float4 pv = mvs_dyn_lds4[MVS_PIVOT_LDS4 + k];
-        const bool more = k + 1 < n;
-        ClsFrame fn;
-        if (more) fn = cls_frame(fb + k + 1);
+        const ClsFrame fn = cls_frame(fb + min(k + 1, n - 1));
         float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f, s2 = 0.0f, s01 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            if (j < nl) {
-                float r, g, b;
-                cls_colour(pend[j], wc.cs[j], pv.x, pv.y, pv.z, r, g, b);
-                if (more) pend[j] = cls_issue(fn, wc.cs[j]);
-                if (k == 0) { c0[j][0] = r; c0[j][1] = g; c0[j][2] = b; }
-                s1r += r; s1g += g; s1b += b;
-                s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
-                s01 = fma_(r, c0[j][0], s01); s01 = fma_(g, c0[j][1], s01); s01 = fma_(b, c0[j][2], s01);
-            }
+            const unsigned cs = cls_opaque(cc.cs[j]);
+            float r, g, b;
+            cls_colour(pend[j], cs, pv.x, pv.y, pv.z, r, g, b);
+            pend[j] = cls_issue(fn, cs);
+            s1r += r; s1g += g; s1b += b;
+            s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
+            s01 = fma_(r, c0[j][0], s01); s01 = fma_(g, c0[j][1], s01); s01 = fma_(b, c0[j][2], s01);
         }
         // the extras lane's sums join lane 16 g + e, then the row tree (lanes 1, 2, 4, 8 apart)
-        s1r = fma_(bperm_f(wc.cpull, s1r), wc.cpullm, s1r);
-        s1g = fma_(bperm_f(wc.cpull, s1g), wc.cpullm, s1g);
-        s1b = fma_(bperm_f(wc.cpull, s1b), wc.cpullm, s1b);
-        s2 = fma_(bperm_f(wc.cpull, s2), wc.cpullm, s2);
-        s01 = fma_(bperm_f(wc.cpull, s01), wc.cpullm, s01);
+        s1r = fma_(bperm_f(cc.pull, s1r), cc.pullm, s1r);
+        s1g = fma_(bperm_f(cc.pull, s1g), cc.pullm, s1g);
+        s1b = fma_(bperm_f(cc.pull, s1b), cc.pullm, s1b);
+        s2 = fma_(bperm_f(cc.pull, s2), cc.pullm, s2);
+        s01 = fma_(bperm_f(cc.pull, s01), cc.pullm, s01);
         MVS_ROW_STEP5(0xB1) MVS_ROW_STEP5(0x4E) MVS_ROW_STEP5(0x141) MVS_ROW_STEP5(0x140)
         if (lc == k) { P1r = s1r; P1g = s1g; P1b = s1b; P2 = s2; P01 = s01; }
     }
@@ -993,7 +1038,7 @@ DEV double cost_of_group(const DParams& prm, const WaveCtx& wc, unsigned okm, fl
     return ans / (double)denom;
 }
 DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int imgx, int n, bool three, float x0, float x1, float x2,
-                    double& f0, double& f1, double& f2, float* piv = nullptr) {
+                    double& f0, double& f1, double& f2, float* piv = nullptr, const ClsConst* cc = nullptr) {
     F4 coord, normal, px, py;
     decode(prm, rc, x0, x1, x2, coord, normal);
     get_paxes(prm, prm.views + rc.ref, coord, normal, px, py);
@@ -1006,7 +1051,7 @@ DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
     if (three) {
         wc.evals += 3;
         unsigned okm[3];
-        eval_steps3(prm, wc, f, sz, okm, incc_l);
+        eval_steps3(prm, wc, *cc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
         // the three means: one fp64 division for all of them (lane j divides the sums of proposal j)
         double a0, a1, a2;
@@ -1053,6 +1098,7 @@ STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, u
     if (wc.lane < 16) mvs_dyn_lds4[MVS_PIVOT_LDS4 + wc.lane] = make_float4(piv[0], piv[1], piv[2], 0.0f);
     __syncthreads();
     double fbest = f0;
+    const ClsConst cc = make_cls(prm, wc);
     float rd = prm.rd0, ra = prm.ra0;
     const int g = wc.lane >> 4;  // this lane's proposal: 0 depth only, 1 angles only, 2 both (3: idle, computes proposal 2 again)
     const uint32_t gj = (uint32_t)min(g, 2);
@@ -1064,7 +1110,7 @@ STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, u
         const float cx0 = (gj == 1u) ? bx0 : fma_(u0, rd, bx0);
         const float cx1 = (gj == 0u) ? bx1 : fmaxf(fminf(fma_(u1, ra, bx1), amax), amin);
         const float cx2 = (gj == 0u) ? bx2 : fmaxf(fminf(fma_(u2, ra, bx2), amax), amin);
-        cost_func3(prm, wc, rc, imgx, c.nimg, true, cx0, cx1, cx2, f0, f1, f2);
+        cost_func3(prm, wc, rc, imgx, c.nimg, true, cx0, cx1, cx2, f0, f1, f2, nullptr, &cc);
         int jb = 0;
         double fstep = f0;
         if (f1 < fstep) { fstep = f1; jb = 1; }
@@ -1293,23 +1339,6 @@ DEV WaveCtx make_wave_ctx(const DParams& prm) {
     wc.fx = (float)(wc.lane % prm.wsize);
     wc.fy = (float)(wc.lane / prm.wsize);
     wc.evals = 0; wc.view_evals = 0;
-    {   // class lanes: which samples this lane walks in eval_steps3
-        const int wsz = prm.wsz, nj = wsz >> 4, rem = wsz & 15;
-        const int rx = rem <= 5 ? rem : 0, njx = nj + (rem > 5 ? 1 : 0);
-        const int row = wc.lane >> 4, c = wc.lane & 15, t = wc.lane - 48;
-        wc.cg = row < 3 ? row : t % 3;
-        const int e = t / 3;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int s = row < 3 ? c + 16 * j : 16 * nj + e;
-            const bool valid = row < 3 ? (j < njx && s < (rem > 5 ? wsz : 16 * nj)) : (j == 0 && e < rx);
-            wc.cs[j] = valid ? (unsigned)(s % prm.wsize) | ((unsigned)(s / prm.wsize) << 8) | (1u << 16) : 0u;
-        }
-        const bool pulls = row < 3 && c < rx;
-        wc.cpull = 4 * (pulls ? 48 + 3 * c + row : wc.lane);
-        wc.cpullm = pulls ? 1.0f : 0.0f;
-        wc.cnl = max(njx, rx ? 1 : 0);
-    }
 #ifdef MVS_STAGE_TIMING
     for (int k = 0; k < 8; ++k) wc.st_acc[k] = 0;
     wc.st_t = 0;
