@@ -402,7 +402,7 @@ DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int
     const GlobalTexels t0 = (GlobalTexels)a0, t1 = (GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)W);
     p.q0.a = t0[0]; p.q0.b = t0[1];
     p.q1.a = t1[0]; p.q1.b = t1[1];
-    p.dx1 = sx - (float)lx; p.dy1 = sy - (float)ly;
+    p.dx1 = __builtin_amdgcn_fractf(sx); p.dy1 = __builtin_amdgcn_fractf(sy);  // == s - (float)(int)s for the non-negative positions sampled
     return p;
 }
 // The same with the frames published in LDS (eval_core): three uniform-address ds_read_b128 (broadcasts, issued on
@@ -439,7 +439,7 @@ DEV Pending tex_issue_lds(const DParams& prm, const WaveCtx& wc, int e) {
     const GlobalTexels t0 = (GlobalTexels)a0, t1 = (GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)W);
     p.q0.a = t0[0]; p.q0.b = t0[1];
     p.q1.a = t1[0]; p.q1.b = t1[1];
-    p.dx1 = sx - (float)lx; p.dy1 = sy - (float)ly;
+    p.dx1 = __builtin_amdgcn_fractf(sx); p.dy1 = __builtin_amdgcn_fractf(sy);  // == s - (float)(int)s for the non-negative positions sampled
     return p;
 }
 // colour - mean on sample lanes (0 elsewhere)
@@ -660,9 +660,10 @@ DEV void cls_colour(const ClsPend& p, unsigned cs, float pr, float pg, float pb,
 }
 DEV float bperm_f(int addr, float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(x))); }
 #define MVS_ROW_STEP(x, C) x = x + dpp_f<C>(x);
-#define MVS_ROW_STEP5(C) { const float t0 = dpp_f<C>(s1r), t1 = dpp_f<C>(s1g), t2 = dpp_f<C>(s1b), t3 = dpp_f<C>(s2), t4 = dpp_f<C>(s01); \
+// (bound_ctrl form: every lane has a source within its row, so no "old" value has to be provided)
+#define MVS_ROW_STEP5(C) { const float t0 = dpp0_f<C>(s1r), t1 = dpp0_f<C>(s1g), t2 = dpp0_f<C>(s1b), t3 = dpp0_f<C>(s2), t4 = dpp0_f<C>(s01); \
                            s1r = s1r + t0; s1g = s1g + t1; s1b = s1b + t2; s2 = s2 + t3; s01 = s01 + t4; }
-#define MVS_ROW_STEP4(C) { const float t0 = dpp_f<C>(s1r), t1 = dpp_f<C>(s1g), t2 = dpp_f<C>(s1b), t3 = dpp_f<C>(s2); \
+#define MVS_ROW_STEP4(C) { const float t0 = dpp0_f<C>(s1r), t1 = dpp0_f<C>(s1g), t2 = dpp0_f<C>(s1b), t3 = dpp0_f<C>(s2); \
                            s1r = s1r + t0; s1g = s1g + t1; s1b = s1b + t2; s2 = s2 + t3; }
 // frames: published in LDS for frame lanes 16 g + k (frames_publish); okm[g] = views of proposal g that sample.
 // Leaves in frame lane 16 g + k (k >= 1) the INCC of view k against the reference view of proposal g.
