@@ -226,7 +226,9 @@ __global__ void k_depth_maps(DParams prm, unsigned long long* __restrict__ dp) {
         if (xs[i] < 0 || vw->gw <= xs[i] || ys[j] < 0 || vw->gh <= ys[j]) continue;
         if (i == 1 && xs[1] == xs[0]) continue;  // same cell twice: idempotent, skip
         if (j == 1 && ys[1] == ys[0]) continue;
-        atomicMin(&dp[vw->cell_base + ys[j] * vw->gw + xs[i]], key);
+        // the cell's value only ever decreases: a plain read that already shows a nearer patch saves the atomic (most do)
+        unsigned long long* cellp = &dp[vw->cell_base + ys[j] * vw->gw + xs[i]];
+        if (key < __builtin_nontemporal_load(cellp)) atomicMin(cellp, key);
     }
 }
 // best-NCC patch per cell among those whose reference view is `view` (parity artefact)
@@ -585,57 +587,98 @@ __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kil
     const float gain = compute_gain(prm, wc, cx, c, s_gain);
     if (wc.lane == 0 && gain < 0.0f) kill[blockIdx.x] = 1;
 }
-// Filter::filterExact, filter.cpp:148-263
+// Filter::filterExact, filter.cpp:148-263.
+// Visibility phase (filterExactSub: PatchManager::isVisible in the patch's cell and its four neighbours, per view of
+// m_images): FOUR patches per wave, lane 16 q + i = view i of patch 4 * block + q.  The five depth-map cells of a lane are
+// loaded together, then the five patches they name, then the five tests run on one ray / unit / factor -- two dependent
+// gathers per lane instead of ten, at four times the lanes per instruction of the one-patch-per-wave form.
+// Then, patch by patch: the surviving views in ascending order and Optim::setRefImage with the whole wave.
+#define MVS_FE_PATCHES 4
 __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage) {
     __shared__ int s_scratch[192];
     extern __shared__ float s_texs[];
-    DPatch* p = prm.pool + blockIdx.x;
-    if (!(p->flags & 1)) return;
     WaveCtx wc = make_wave_ctx(prm);
 #ifdef MVS_STAGE_TIMING
     const unsigned long long fe_begin = (unsigned long long)__builtin_amdgcn_s_memtime();
     WC_T0(wc)
 #endif
-    Cand c;
-    load_cand(p, wc, c);
-    set_grids(prm, wc, c);
+    const int q = wc.lane >> 4, i = wc.lane & 15;
+    const int64_t id = (int64_t)blockIdx.x * MVS_FE_PATCHES + q;
+    const bool have = id < prm.pool_n;
+    const DPatch* pl = prm.pool + (have ? id : 0);
+    const bool alive_l = have && (pl->flags & 1);
+    const int nimg_l = alive_l ? min(pl->nimages, MVS_LISTCAP) : 0;
+    const bool act = i < nimg_l;
+    const int image = act ? (int)pl->images[i] : 0;
+    const F4 coord = ld4(pl->coord), normal = ld4(pl->normal);
     WC_ADD(wc, 5)
-    // view lane i: does view m_images[i] survive?  (filterExactSub: own cell, then the 4 neighbouring cells)
     bool safe = false;
-    if (wc.lane < c.nimg) {
-        const int image = c.img, x = c.gx, y = c.gy;
+    {
         const DView* vw = prm.views + image;
-        const int w = vw->gw, h = vw->gh;
-        if (!(x < 0 || w <= x || y < 0 || h <= y)) {
-            const float thr = prm.neighborThreshold1;
-            safe = is_visible(prm, c, image, x, y, thr) || (0 < x && is_visible(prm, c, image, x - 1, y, thr)) ||
-                   (x < w - 1 && is_visible(prm, c, image, x + 1, y, thr)) || (0 < y && is_visible(prm, c, image, x, y - 1, thr)) ||
-                   (y < h - 1 && is_visible(prm, c, image, x, y + 1, thr));
+        const int w = vw->gw, h = vw->gh, cbase = vw->cell_base;
+        const F4 ctr = ld4(vw->center);
+        const float ips = vw->ipscale;
+        int x, y;
+        cell_of(prm, vw, coord, x, y);  // PatchManager::setGrids
+        const bool in = act && !(x < 0 || w <= x || y < 0 || h <= y);
+        // the five cells of filterExactSub, each behind its guard (filter.cpp:221-251)
+        const int dxs[5] = {0, -1, 1, 0, 0}, dys[5] = {0, 0, 0, -1, 1};
+        bool ok[5];
+        unsigned long long dp[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int xx = x + dxs[k], yy = y + dys[k];
+            ok[k] = in && 0 <= xx && xx < w && 0 <= yy && yy < h;  // the guards 0 < x, x < w-1, ... and isVisible's own range test
+            dp[k] = prm.dpgrid[cbase + (ok[k] ? yy * w + xx : 0)];
+        }
+        F4 qc[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) qc[k] = ld4((prm.pool + (dp[k] == ~0ull ? 0u : (uint32_t)(dp[k] & 0xffffffffull)))->coord);
+        // PatchManager::isVisible, patch_manager.cpp:335-376: everything but the depth difference is the same for the five
+        const F4 ray = nrm4(sub4(coord, ctr));
+        const double factor = fmin(2.0, 2.0 + (double)dot4(ray, normal));
+        float unit = 1.0f;  // get_unit
+        if (ips != 0.0f) unit = (2.0f * norm4(sub4(coord, ctr)) * (float)(1 << prm.level)) / ips;
+        const double rhs = (double)(unit * (float)prm.csize * prm.neighborThreshold1) * factor;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float diff = dot4(ray, sub4(coord, qc[k]));
+            const bool vis = prm.depth == 0 || dp[k] == ~0ull || (double)diff < rhs;
+            safe |= ok[k] && vis;
         }
     }
     WC_ADD(wc, 6)
-    // the survivors in ascending view order (the image-major loop of filterExactSub)
-    __syncthreads();
-    if (wc.lane < MVS_MAXVIEWS) s_scratch[wc.lane] = 0;
-    __syncthreads();
-    if (safe) s_scratch[c.img] = 1;
-    __syncthreads();
-    const bool present = s_scratch[wc.lane] != 0;
-    const unsigned long long pm = ballot(present);
-    const int pos = __popcll(pm & ((1ull << wc.lane) - 1ull));
-    __syncthreads();
-    if (present && pos < MVS_LISTCAP) s_scratch[64 + pos] = wc.lane;
-    __syncthreads();
-    c.nimg = min((int)__popcll(pm), MVS_LISTCAP);
-    c.img = s_scratch[64 + wc.lane];
-    if (prm.minImageNum <= c.nimg) {
-        const int tstride = prm.wsz;  // odd for 7x7 / 5x5 windows: the lane-per-pair reads of setRefImage fall in distinct banks
-        set_ref_image(prm, wc, s_texs, tstride, c);
-        store_lists(p, wc, c);
-    } else {
-        if (wc.lane == 0) kill[blockIdx.x] = 1;
+    const unsigned long long safe_b = ballot(safe);
+    const unsigned long long alive_b = ballot(alive_l);
+    const int tstride = prm.wsz;  // odd for 7x7 / 5x5 windows: the lane-per-pair reads of setRefImage fall in distinct banks
+    for (int g = 0; g < MVS_FE_PATCHES; ++g) {
+        if (!((alive_b >> (16 * g)) & 1ull)) continue;
+        DPatch* p = prm.pool + ((int64_t)blockIdx.x * MVS_FE_PATCHES + g);
+        Cand c;
+        load_cand(p, wc, c);
+        const unsigned sm = (unsigned)((safe_b >> (16 * g)) & 0xffffull);  // bit i: view m_images[i] of patch g survives
+        // the survivors in ascending view order (the image-major loop of filterExactSub)
+        __syncthreads();
+        if (wc.lane < MVS_MAXVIEWS) s_scratch[wc.lane] = 0;
+        __syncthreads();
+        if (wc.lane < c.nimg && ((sm >> wc.lane) & 1u)) s_scratch[c.img] = 1;
+        __syncthreads();
+        const bool present = s_scratch[wc.lane] != 0;
+        const unsigned long long pm = ballot(present);
+        const int pos = __popcll(pm & ((1ull << wc.lane) - 1ull));
+        __syncthreads();
+        if (present && pos < MVS_LISTCAP) s_scratch[64 + pos] = wc.lane;
+        __syncthreads();
+        c.nimg = min((int)__popcll(pm), MVS_LISTCAP);
+        c.img = s_scratch[64 + wc.lane];
+        if (prm.minImageNum <= c.nimg) {
+            set_ref_image(prm, wc, s_texs, tstride, c);
+            store_lists(p, wc, c);
+        } else {
+            if (wc.lane == 0) kill[(int64_t)blockIdx.x * MVS_FE_PATCHES + g] = 1;
+        }
     }
-    if (wc.lane == 0) { atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
+    if (wc.lane == 0 && wc.evals) { atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
 #ifdef MVS_STAGE_TIMING
     if (stage && wc.lane == 0) {
         atomicAdd(stage, (unsigned long long)__builtin_amdgcn_s_memtime() - fe_begin);
@@ -885,7 +928,7 @@ void mvsk_filter_outside(const DParams& prm, uint8_t* kill, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_outside, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, kill);
 }
 void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)prm.pool_n), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals, stage);
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)((prm.pool_n + MVS_FE_PATCHES - 1) / MVS_FE_PATCHES)), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals, stage);
 }
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, hipStream_t st) {
     if (prm.pool_n <= 0) return;
