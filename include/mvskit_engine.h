@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define MVS_MAX_IMAGES 32 /* storage of Patch::m_images / m_vimages in a record */
-#define MVS_LIST_CAP 16   /* lists are truncated to this many views (engine limit) */
+#define MVS_LIST_CAP 16   /* lists are truncated to this many views in the default build; see mvs_list_cap() */
 
 typedef enum mvs_status {
     MVS_OK = 0,
@@ -108,6 +108,11 @@ typedef struct mvs_engine mvs_engine;
 
 const char* mvs_last_error(void);
 int mvs_device_count(void);
+/* Patch::m_images / m_vimages are unbounded in the reference (optim.cpp:165-205 pushes every qualifying view); the engine
+ * keeps them in wavefront lanes and LDS and truncates them: to 16 views in libmvskit_engine.so, to 32 in
+ * libmvskit_engine_cap32.so (the same sources built with -DMVS_LISTCAP=32: twice the setRefImage LDS, 2 waves per SIMD),
+ * which is the library to load for data sets of more than 16 views. */
+int mvs_list_cap(void);
 void mvs_default_config(mvs_config* cfg); /* Option::Option, option.cpp:19-33 */
 
 /* PmMvps::init (pmmvps.cpp:18-68): thresholds, tau = min(2*minImageNum, nviews), maxLevel = level+3 */

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmvskit_engine.so")
+LIB32_PATH = os.path.join(LIB_DIR, "libmvskit_engine_cap32.so")  # the same sources with 32-view lists (-DMVS_LISTCAP=32)
 SOURCES = ["mvs_kernels.hip", "mvs_engine.cpp"]
 DEPS = SOURCES + ["mvs_device.cuh", "mvs_check.cuh", "mvs_types.h", "mvs_kernels.h", os.path.join(ROOT, "include", "mvskit_engine.h")]
 
@@ -20,12 +21,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wno-implicit-const-int-float-conversion"]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def needs_build(path: str = LIB_PATH) -> bool:
+    if not os.path.exists(path):
         return True
     if os.environ.get("GRAFT_REPO_ROOT"):  # on a GPU box the snapshot's prebuilt library is used as is
         return False
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     for d in DEPS:
         p = d if os.path.isabs(d) else os.path.join(CSRC, d)
         if os.path.getmtime(p) > t:
@@ -33,17 +34,19 @@ def needs_build() -> bool:
     return False
 
 
-def build_engine(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB_PATH
+def build_engine(force: bool = False, verbose: bool = False, cap32: bool = False) -> str:
+    out = LIB32_PATH if cap32 else LIB_PATH
+    if not force and not needs_build(out):
+        return out
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + os.environ.get("MVS_EXTRA_FLAGS", "").split() + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH, "-ldl"]
+    cmd = [hipcc] + FLAGS + (["-DMVS_LISTCAP=32"] if cap32 else []) + os.environ.get("MVS_EXTRA_FLAGS", "").split()
+    cmd += ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 HOST_DIR = os.path.join(HERE, "host")
@@ -68,4 +71,5 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build_engine(force=True, verbose=True))
+    print(build_engine(force=True, verbose=True, cap32=True))
     print(build_host(force=True, verbose=True))

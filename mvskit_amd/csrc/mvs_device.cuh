@@ -503,7 +503,7 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
     Pending pr[NP], pn[NS];
     unsigned okv[NP];  // per-lane copies of the (uniform) masks: the ok flags come back from LDS in vector registers
 #if MVS_FRAME_LDS
-    frames_publish(wc, f, 16 * NP);
+    frames_publish(wc, f, NP == 1 ? (MVS_LISTCAP > 16 ? MVS_LISTCAP : 16) : 16 * NP);  // a single proposal may span a whole list (setINCCs), three proposals span tau <= 16 views each
 #define TEX_ISSUE(e) tex_issue_lds(prm, wc, e)
 #else
 #define TEX_ISSUE(e) tex_issue(prm, wc, f, e)
@@ -1194,11 +1194,13 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     const float inv_l = inv_msd(prm, ssd_l);
     WC_ADD(wc, 2)
     __syncthreads();
-    // one lane per pair (a, b), a < b < n; up to 120 pairs = 2 rounds of 64 lanes
+    // one lane per pair (a, b), a < b < n: 120 pairs = 2 rounds of 64 lanes for 16 views (496 = 8 rounds for 32); the
+    // robust INCC of pair q goes to LDS behind the textures
     const int npairs = n * (n - 1) / 2;
-    float val0 = 2.0f, val1 = 2.0f;  // robust INCC of pair lane + 64 * round
+    float* pairv = texs + MVS_LISTCAP * 3 * tstride;
     for (int r = 0; r * 64 < npairs; ++r) {
-        int q = wc.lane + 64 * r;
+        const int q0 = wc.lane + 64 * r;
+        int q = q0;
         const bool act = q < npairs;
         int a = 0;
         if (act) { while (q >= n - 1 - a) { q -= n - 1 - a; ++a; } }
@@ -1211,8 +1213,9 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
         const float inva = __shfl(inv_l, a), invb = __shfl(inv_l, b);
         float val = robustincc(1.0f - (acc * (inva * invb)) * prm.inv_3sz);
         if (!(act && ((okmask >> a) & 1u) && ((okmask >> b) & 1u))) val = 2.0f;
-        if (r == 0) val0 = val; else val1 = val;
+        if (act) pairv[q0] = val;
     }
+    __syncthreads();
     WC_ADD(wc, 3)
     // view lane i: sum over j of inccs[i][j], j ascending (std::accumulate, optim.cpp:368)
     float acc = 0.0f;
@@ -1220,8 +1223,7 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
         const int i = min(wc.lane, n - 1);
         const int a = min(i, j), b = max(i, j);
         const int q = a < b ? pair_index(a, b, n) : 0;
-        const float v0 = __shfl(val0, q & 63), v1 = __shfl(val1, q & 63);
-        const float v = (q >> 6) ? v1 : v0;
+        const float v = pairv[q];
         if (wc.lane < n && wc.lane != j) acc += v;
     }
     const float big = (float)(INT_MAX / 2);

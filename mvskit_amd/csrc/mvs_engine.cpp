@@ -17,7 +17,7 @@
 #include "mvs_types.h"
 
 static_assert(sizeof(mvs_patch) == sizeof(DPatch), "mvs_patch and DPatch must be the same bytes");
-static_assert(MVS_LIST_CAP >= MVS_LISTCAP && MVS_MAX_IMAGES == MVS_MAXI, "limits out of sync");
+static_assert((MVS_LISTCAP == 16 || MVS_LISTCAP == 32) && MVS_LISTCAP <= MVS_MAXI && MVS_MAX_IMAGES == MVS_MAXI, "limits out of sync");
 
 namespace {
 thread_local std::string g_err;
@@ -408,6 +408,8 @@ extern "C" {
 
 const char* mvs_last_error(void) { return g_err.c_str(); }
 
+int mvs_list_cap(void) { return MVS_LISTCAP; }
+
 int mvs_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -427,8 +429,8 @@ int mvs_engine_create(const mvs_config* cfg, mvs_engine** out) {
     if (cfg->shard_count > 1 && (cfg->shard_index < 0 || cfg->shard_index >= cfg->shard_count)) { g_err = "mvs_engine_create: bad shard_index"; return MVS_ERR_ARG; }
     if (cfg->nviews < 1 || cfg->nviews > MVS_MAXVIEWS || cfg->wsize < 1 || cfg->wsize > 7 || cfg->csize < 1 || cfg->level < 0 ||
         cfg->level > 4 || cfg->max_propag < 1 || cfg->max_propag > 16 || cfg->max_propag * cfg->csize * cfg->csize > MVS_CAPMAX ||
-        cfg->view_stride < 1 || cfg->view_begin < 0 || cfg->minImageNum < 1) {
-        g_err = "mvs_engine_create: configuration out of range (nviews <= 64, wsize <= 7, max_propag*csize^2 <= 32)";
+        cfg->view_stride < 1 || cfg->view_begin < 0 || cfg->minImageNum < 1 || cfg->minImageNum > 8 /* tau = 2 minImageNum views sit in 16 frame lanes */) {
+        g_err = "mvs_engine_create: configuration out of range (nviews <= 64, wsize <= 7, minImageNum <= 8, max_propag*csize^2 <= 32)";
         return MVS_ERR_ARG;
     }
     int ndev = 0;
@@ -600,7 +602,7 @@ int mvs_engine_upload_patches(mvs_engine* e, int64_t n, const mvs_patch* patches
     recs.reserve((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         mvs_patch p = patches[i];
-        p.nimages = std::min(p.nimages, MVS_LIST_CAP);
+        p.nimages = std::min(p.nimages, MVS_LISTCAP);
         if (p.nimages <= 0) continue;
         memset(p.images + p.nimages, 0, sizeof p.images - (size_t)p.nimages);  // entries past the (truncated) list are not data
         p.nvimages = 0;

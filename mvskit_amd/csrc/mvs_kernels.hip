@@ -593,7 +593,8 @@ __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kil
 // loaded together, then the five patches they name, then the five tests run on one ray / unit / factor -- two dependent
 // gathers per lane instead of ten, at four times the lanes per instruction of the one-patch-per-wave form.
 // Then, patch by patch: the surviving views in ascending order and Optim::setRefImage with the whole wave.
-#define MVS_FE_PATCHES 4
+#define MVS_FE_LANES (MVS_LISTCAP <= 16 ? 16 : 32)  // lanes per patch in the visibility phase
+#define MVS_FE_PATCHES (64 / MVS_FE_LANES)
 __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage) {
     __shared__ int s_scratch[192];
     extern __shared__ float s_texs[];
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
     const unsigned long long fe_begin = (unsigned long long)__builtin_amdgcn_s_memtime();
     WC_T0(wc)
 #endif
-    const int q = wc.lane >> 4, i = wc.lane & 15;
+    const int q = wc.lane / MVS_FE_LANES, i = wc.lane % MVS_FE_LANES;
     const int64_t id = (int64_t)blockIdx.x * MVS_FE_PATCHES + q;
     const bool have = id < prm.pool_n;
     const DPatch* pl = prm.pool + (have ? id : 0);
@@ -652,11 +653,11 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
     const unsigned long long alive_b = ballot(alive_l);
     const int tstride = prm.wsz;  // odd for 7x7 / 5x5 windows: the lane-per-pair reads of setRefImage fall in distinct banks
     for (int g = 0; g < MVS_FE_PATCHES; ++g) {
-        if (!((alive_b >> (16 * g)) & 1ull)) continue;
+        if (!((alive_b >> (MVS_FE_LANES * g)) & 1ull)) continue;
         DPatch* p = prm.pool + ((int64_t)blockIdx.x * MVS_FE_PATCHES + g);
         Cand c;
         load_cand(p, wc, c);
-        const unsigned sm = (unsigned)((safe_b >> (16 * g)) & 0xffffull);  // bit i: view m_images[i] of patch g survives
+        const unsigned sm = (unsigned)((safe_b >> (MVS_FE_LANES * g)) & ((1ull << MVS_FE_LANES) - 1ull));  // bit i: view m_images[i] of patch g survives
         // the survivors in ascending view order (the image-major loop of filterExactSub)
         __syncthreads();
         if (wc.lane < MVS_MAXVIEWS) s_scratch[wc.lane] = 0;
@@ -885,7 +886,8 @@ void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_fill_ncc, dim3((unsigned)((prm.pool_n + 63) / 64)), dim3(64), MVS_FRAME_LDS_BYTES, st, prm, evals);
 }
 size_t mvsk_sweep_lds_bytes(const DParams& prm) {
-    const size_t texs = (size_t)MVS_LISTCAP * 3 * prm.wsz * sizeof(float);  // setRefImage textures: 9408 B at wsize 7
+    // setRefImage: the centred textures of MVS_LISTCAP views (9408 B at wsize 7 and 16 views) + one value per view pair
+    const size_t texs = ((size_t)MVS_LISTCAP * 3 * prm.wsz + (size_t)MVS_LISTCAP * (MVS_LISTCAP - 1) / 2) * sizeof(float);
     const size_t chk = (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float);                      // Optim::check hash set + rows
     return texs > chk ? texs : chk;
 }

@@ -22,7 +22,7 @@ EXPORTS = [
     "mvs_engine_pass", "mvs_engine_export_counts", "mvs_engine_export_device", "mvs_engine_commit_device",
     "mvs_engine_commit_local", "mvs_engine_depth_normal_map", "mvs_engine_probe", "mvs_engine_last_timing",
     "mvs_engine_filter", "mvs_comm_unique_id", "mvs_engine_comm_init", "mvs_engine_comm_attach", "mvs_engine_comm_release",
-    "mvs_engine_exchange",
+    "mvs_engine_exchange", "mvs_list_cap",
 ]
 
 
@@ -58,15 +58,16 @@ class EngineError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Loads libmvskit_engine.so (built in-tree by mvskit_amd.build / __graft_entry__.build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    LIB_PATH = os.environ.get("MVS_ENGINE_LIB", build.LIB_PATH)  # development: A/B timing of two builds on one box
+def load_library(cap32: bool = False):
+    """Loads libmvskit_engine.so -- or, for view lists of up to 32 entries, libmvskit_engine_cap32.so (the same sources
+    built with -DMVS_LISTCAP=32) -- built in-tree by mvskit_amd.build / __graft_entry__.build."""
+    default = build.LIB32_PATH if cap32 else build.LIB_PATH
+    LIB_PATH = default if cap32 else os.environ.get("MVS_ENGINE_LIB", default)  # development: A/B timing of two builds on one box
+    if LIB_PATH in _libs:
+        return _libs[LIB_PATH]
     if not os.path.exists(LIB_PATH):
         raise EngineError(f"{LIB_PATH} is missing: run `python -m mvskit_amd.build` (the engine has no CPU fallback)")
     try:
@@ -107,7 +108,8 @@ def load_library():
     L.mvs_engine_comm_attach.argtypes = [vp, vp, C.c_int, C.c_int]
     L.mvs_engine_comm_release.argtypes = [vp]
     L.mvs_engine_exchange.argtypes = [vp]
-    _lib = L
+    L.mvs_list_cap.restype = C.c_int
+    _libs[LIB_PATH] = L
     return L
 
 
@@ -118,8 +120,12 @@ def _ptr(a):
 class Engine:
     """One PmMvps instance whose Propagate::run lives on an MI355X (pmmvps/pmmvps.cpp:76-114)."""
 
-    def __init__(self, nviews, **kw):
-        self.L = load_library()
+    def __init__(self, nviews, list_cap=None, **kw):
+        """list_cap: 16 or 32 views per m_images / m_vimages list (which library); default 16 up to 16 views, else 32."""
+        if list_cap is None:
+            list_cap = 32 if nviews > 16 else 16
+        self.L = load_library(cap32=list_cap > 16)
+        self.list_cap = self.L.mvs_list_cap()
         self.cfg = Config()
         self.L.mvs_default_config(C.byref(self.cfg))
         self.cfg.nviews = nviews

@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -42,8 +43,16 @@ namespace {
 
 thread_local std::string g_err;
 
+/* Storage of Patch::m_images / m_vimages inside the restatement.  The default build stores what a record holds (32); the
+ * "wide" build (make wide: -DORC_WIDE_LISTS) stores 64, enough for the reference's unbounded lists on a 48-view scene, and
+ * exists to measure what the engine's 16-view truncation costs (tests/test_oracle_kat.py::test_list_cap_48_views). */
+#ifdef ORC_WIDE_LISTS
+constexpr int MAXI = 64;
+#else
 constexpr int MAXI = ORC_MAX_IMAGES;
-constexpr int LISTCAP = 16; /* engine limit: m_images / m_vimages are truncated to 16 views */
+#endif
+constexpr int LISTCAP_DEFAULT = 16; /* engine limit: m_images / m_vimages are truncated to 16 views (orc_config.list_cap overrides) */
+#define LISTCAP (s.list_cap)
 constexpr int NEWBASE = 0x40000000; /* provisional ids of patches staged by a destination cell */
 
 /* ------------------------------------------------------------------ small vectors */
@@ -221,6 +230,8 @@ struct Scene {
     /* engine: CSR snapshot */
     std::vector<std::vector<int>> csr_start, csr_ids, vcsr_start, vcsr_ids;
     std::vector<DestCtx> staged_cells; /* results of the last engine pass, order (view, cell) */
+    int list_cap = LISTCAP_DEFAULT;              /* m_images / m_vimages are truncated to this many views */
+    mutable std::atomic<int64_t> list_truncations{0}; /* addImages / setVImagesVGrids / filterExact calls that wanted a longer list */
     int64_t cell_budget = 0;
     double last_sweep_seconds = 0.0; /* engine schedule: wall time of the last colour pass's parallel loop */
     double time_budget = 0.0; /* stop the sweep (faithful) / the colour pass (engine) after this many seconds (0 = off) */
@@ -649,7 +660,10 @@ void add_images(const Scene& s, Patch& p) {
         if (ic.x < 0.0f || vw.W[s.cfg.level] - 1 <= ic.x || ic.y < 0.0f || vw.H[s.cfg.level] - 1 <= ic.y) continue;
         V4 ray = sub4(vw.center, p.coord);
         ray = nrm4(ray);
-        if (s.cosAngle0 <= dot4(ray, p.normal) && p.nimg < LISTCAP) p.img[p.nimg++] = v;
+        if (s.cosAngle0 <= dot4(ray, p.normal)) {
+            if (p.nimg < LISTCAP) p.img[p.nimg++] = v;
+            else s.list_truncations.fetch_add(1, std::memory_order_relaxed);
+        }
     }
 }
 
@@ -1050,6 +1064,7 @@ void set_vimages_vgrids(const Scene& s, Patch& p, const DestCtx* ctx) {
         cell_of(s, image, p.coord, ix, iy);
         if (is_visible(s, p, image, ix, iy, s.neighborThreshold, ctx) == 0) continue;
         if (p.nvimg < LISTCAP) { p.vimg[p.nvimg] = image; p.vgx[p.nvimg] = ix; p.vgy[p.nvimg] = iy; ++p.nvimg; }
+        else s.list_truncations.fetch_add(1, std::memory_order_relaxed);
     }
 }
 
@@ -1507,7 +1522,7 @@ int post_process(const Scene& s, Patch& p, const DestCtx* ctx, orc_counters* cnt
  * only (propagate.cpp:170) and overwritten by refinePatch, so the engine does not compute it when nothing reads it. */
 bool generate_patch(const Scene& s, const Patch& src, const V3& icoord, Patch& out, orc_counters* cnt, int as_image = -1, bool need_ncc = true) {
     out = Patch();
-    int images[LISTCAP];
+    int images[MAXI];
     for (int i = 0; i < src.nimg; ++i) images[i] = src.img[i];
     if (as_image >= 0 && images[0] != as_image) {
         int k = -1;
@@ -1903,15 +1918,15 @@ void to_rec(const Patch& p, int id, orc_patch& r) {
     r.normal[0] = p.normal.x; r.normal[1] = p.normal.y; r.normal[2] = p.normal.z; r.normal[3] = p.normal.w;
     r.ncc = p.ncc; r.dscale = p.dscale; r.ascale = p.ascale; r.tmp = p.tmp;
     r.nimages = p.nimg; r.nvimages = p.nvimg; r.flags = p.alive ? 1 : 0; r.id = id;
-    for (int i = 0; i < p.nimg; ++i) r.images[i] = (uint8_t)p.img[i];
-    for (int i = 0; i < p.nvimg; ++i) r.vimages[i] = (uint8_t)p.vimg[i];
+    for (int i = 0; i < std::min(p.nimg, (int)ORC_MAX_IMAGES); ++i) r.images[i] = (uint8_t)p.img[i];   /* a record holds 32 (wide build: the tail is cut) */
+    for (int i = 0; i < std::min(p.nvimg, (int)ORC_MAX_IMAGES); ++i) r.vimages[i] = (uint8_t)p.vimg[i];
 }
-void from_rec(const orc_patch& r, Patch& p) {
+void from_rec(const Scene& s, const orc_patch& r, Patch& p) {
     p = Patch();
     p.coord = {r.coord[0], r.coord[1], r.coord[2], r.coord[3]};
     p.normal = {r.normal[0], r.normal[1], r.normal[2], r.normal[3]};
     p.ncc = r.ncc; p.dscale = r.dscale; p.ascale = r.ascale; p.tmp = r.tmp;
-    p.nimg = std::min(r.nimages, LISTCAP); p.nvimg = std::min(r.nvimages, LISTCAP);
+    p.nimg = std::min(std::min(r.nimages, LISTCAP), (int)ORC_MAX_IMAGES); p.nvimg = std::min(std::min(r.nvimages, LISTCAP), (int)ORC_MAX_IMAGES);
     for (int i = 0; i < p.nimg; ++i) p.img[i] = r.images[i];
     for (int i = 0; i < p.nvimg; ++i) p.vimg[i] = r.vimages[i];
     p.alive = true;
@@ -1941,6 +1956,7 @@ void derive_thresholds(Scene& s) { /* PmMvps::init, pmmvps.cpp:32-36,54-67 */
     s.tau = std::min(c.minImageNum * 2, c.nviews);
     s.maxLevel = c.level + 3;
     s.cap = c.max_propag * c.csize * c.csize;
+    s.list_cap = c.list_cap > 0 ? std::min(c.list_cap, MAXI) : LISTCAP_DEFAULT;
     s.nccThreshold = c.nccThreshold;
     s.nccThresholdBefore = c.nccThreshold - 0.3f;
     s.angleThreshold0 = (float)(60.0f * M_PI / 180.0f);
@@ -2064,7 +2080,7 @@ int orc_add_patches(orc_scene* h, int n, const orc_patch* recs) { /* readPatches
     if (!s.finalized) { g_err = "orc_add_patches: views not finalized"; return -1; }
     for (int k = 0; k < n; ++k) {
         Patch p;
-        from_rec(recs[k], p);
+        from_rec(s, recs[k], p);
         if (p.nimg == 0) continue;
         p.tmp = score2(p, s.nccThreshold);
         p.nvimg = 0;
@@ -2090,6 +2106,8 @@ int orc_clear_patches(orc_scene* h) {
     if (h->s.finalized) orc_finalize_views(h);
     return 0;
 }
+int64_t orc_list_truncations(orc_scene* h) { return h->s.list_truncations.load(); }
+int orc_list_storage(void) { return MAXI; }
 int orc_set_cell_budget(orc_scene* h, int64_t n) { h->s.cell_budget = n; return 0; }
 int orc_set_time_budget(orc_scene* h, double seconds) { h->s.time_budget = seconds; return 0; }
 double orc_last_sweep_seconds(orc_scene* h) { return h->s.last_sweep_seconds; }
@@ -2123,7 +2141,7 @@ int orc_commit(orc_scene* h, int n_new, const orc_patch* recs, int n_kill, const
     for (int k = 0; k < n_kill; ++k) if (kill_ids[k] >= 0 && kill_ids[k] < (int)s.pool.size()) s.pool[kill_ids[k]].alive = false;
     for (int k = 0; k < n_new; ++k) {
         Patch p;
-        from_rec(recs[k], p);
+        from_rec(s, recs[k], p);
         set_grids(s, p); set_vgrids(s, p);
         s.pool.push_back(p);
     }
@@ -2199,7 +2217,7 @@ int orc_depth_normal_map(orc_scene* h, int view, int kind, float* depth, float* 
 
 /* ---------------------------------------------------------------- probes */
 static V4 v4(const float* a) { return {a[0], a[1], a[2], a[3]}; }
-static void prep_probe(Scene& s, const orc_patch* r, Patch& p) { from_rec(*r, p); set_grids(s, p); set_vgrids(s, p); }
+static void prep_probe(Scene& s, const orc_patch* r, Patch& p) { from_rec(s, *r, p); set_grids(s, p); set_vgrids(s, p); }
 
 int orc_project(orc_scene* h, int v, const float* c, int level, float* ic) {
     const V3 r = project(h->s.views[v], v4(c), level); ic[0] = r.x; ic[1] = r.y; ic[2] = r.z; return 0;

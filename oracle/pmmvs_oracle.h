@@ -68,6 +68,8 @@ typedef struct orc_config {
     int32_t view_propagation; /* engine schedule only: the disabled branch of propagate.cpp:110-120 (see dest_cell_engine) */
     int32_t shard_index;  /* engine schedule, shard_count > 1: sweep the shard_index-th of shard_count contiguous ranges */
     int32_t shard_count;  /*   of the destination cells of all views (view_begin / view_stride ignored) */
+    int32_t list_cap;     /* m_images / m_vimages are truncated to this many views; 0 = 16, the engine's limit (MVS_LIST_CAP).
+                           * Values above 32 need the wide build (make -C oracle wide), see orc_list_storage() */
     int32_t literal_evals; /* engine schedule only, 1 = no evaluation shortcuts: the initial m_ncc of every candidate
                             * (propagate.cpp:235), refinePatch's own final computeINCC (optim.cpp:541) and the second
                             * constraintImages of postProcess (optim.cpp:286) are always evaluated, as the reference does.
@@ -115,6 +117,8 @@ int orc_propagate(orc_scene* s, int iter, orc_counters* out);  /* Propagate::run
 /* Filter::run (filter.cpp:25-49): removed4 = patches removed by filterOutside / Exact / Neighbor / SmallGroups */
 int orc_filter(orc_scene* s, int64_t* removed4);
 /* faithful schedule only: bound the work (for timing a sample). <=0 means unlimited. */
+int64_t orc_list_truncations(orc_scene* s); /* times a view list wanted to grow past list_cap since orc_create */
+int orc_list_storage(void);                 /* views a list can hold in this build: 32, or 64 in the wide build */
 int orc_set_cell_budget(orc_scene* s, int64_t max_source_cells);
 int orc_set_time_budget(orc_scene* s, double seconds);
 double orc_last_sweep_seconds(orc_scene* h); /* engine schedule: wall time of the last colour pass's parallel loop */

@@ -31,7 +31,7 @@ class Config(C.Structure):
                 ("refine_rd0", C.c_float), ("refine_ra0", C.c_float), ("enable_check", C.c_int32),
                 ("view_begin", C.c_int32), ("view_stride", C.c_int32), ("nthreads", C.c_int32),
                 ("view_propagation", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
-                ("literal_evals", C.c_int32)]
+                ("list_cap", C.c_int32), ("literal_evals", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -80,6 +80,9 @@ def lib():
     L.orc_clear_patches.argtypes = [vp]
     L.orc_propagate.argtypes = [vp, C.c_int, C.POINTER(Counters)]
     L.orc_filter.argtypes = [vp, vp]
+    L.orc_list_truncations.argtypes = [vp]
+    L.orc_list_truncations.restype = C.c_int64
+    L.orc_list_storage.restype = C.c_int
     L.orc_set_cell_budget.argtypes = [vp, C.c_int64]
     L.orc_set_time_budget.argtypes = [vp, C.c_double]
     L.orc_engine_pass.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Counters)]

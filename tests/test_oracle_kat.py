@@ -287,3 +287,28 @@ def test_engine_shortcuts_leave_patches_identical(small_multi_scene):
     assert saved > 1000
     short.close()
     lit.close()
+
+
+def test_list_cap_48_views():
+    """the reference's m_images is unbounded (optim.cpp:165-205); the engine truncates it to 16 views, or to 32
+    in the cap32 build that engine.Engine picks for more than 16 views.  On a 48-view scene (BASELINE configs[3] has 48) the
+    wide build of the oracle (64 views per list = untruncated here) measures what each cap costs: tests/listcap_probe.py."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(here), "oracle"), "-s", "wide"])
+    env = dict(os.environ, MVS_ORACLE_LIB=os.path.join(os.path.dirname(here), "oracle", "_build", "liboracle_wide.so"))
+    out = subprocess.run([sys.executable, os.path.join(here, "listcap_probe.py")], env=env, check=True, capture_output=True, text=True).stdout
+    r = json.loads(out.strip().split("\n")[-1])
+    assert r["cap64"]["truncations"] == 0 and r["cap64"]["max_nimages"] > 32  # 64 slots hold every list the reference would build
+    assert r["cap16"]["truncations"] > 1000000                                 # 16 do not, by far: lists of 48-view patches want ~23 views
+    assert r["cap32"]["truncations"] < r["cap16"]["truncations"] / 4
+    a16, a32 = r["cap16_vs_untruncated"], r["cap32_vs_untruncated"]
+    f16 = a16["cells_within_1e-3"] / max(a16["cells_both"], 1)
+    f32 = a32["cells_within_1e-3"] / max(a32["cells_both"], 1)
+    # the truncation is visible in the depth / normal maps: with 16 views a quarter of the cells agree with the untruncated
+    # run to 1e-3, with 32 views over half (and the median difference is zero) -- which is why data sets of more than 16
+    # views run on the 32-view build
+    assert f32 > 0.5 and f32 > 2.0 * f16, (f16, f32)
+    assert a32["median_rel_depth_diff"] <= 1e-6 and a16["median_rel_depth_diff"] < 5e-3
