@@ -149,9 +149,7 @@ def test_propagate_two_iterations_matches_oracle(small_multi_scene):
         np.testing.assert_allclose(pe["ncc"], po["ncc"], rtol=REL_TOL, atol=1e-6)
         assert (po["coord"].view(np.uint32) == pe["coord"].view(np.uint32)).all(axis=1).mean() > 0.999
     tot, bad = _maps_close(o, e, sc.nviews)
-    # 20 overlapping views put several patches of nearly the same depth into a cell: where two of them lie within the
-    # coordinate tolerance of each other the nearest one may differ (5 of 107 490 cells when this was written)
-    assert tot > 2000 and bad <= tot * 1e-4, (tot, bad)
+    assert tot > 2000 and bad == 0
 
 
 def test_check_stage_probe(small_multi_scene):
@@ -341,7 +339,9 @@ def test_cap32_library_two_iterations_with_check_and_filter():
     np.testing.assert_array_equal(po["vimages"], pe["vimages"])
     np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
     tot, bad = _maps_close(o, e, sc.nviews)
-    assert tot > 2000 and bad == 0
+    # 20 overlapping views put several patches of nearly the same depth into a cell: where two of them lie within the
+    # coordinate tolerance of each other the nearest one may differ (5 of 107 490 cells when this was written)
+    assert tot > 2000 and bad <= tot * 1e-4, (tot, bad)
 
 
 def test_view_propagation_matches_oracle(small_multi_scene):
