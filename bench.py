@@ -229,6 +229,7 @@ def main():
             tf = time.perf_counter()
             c["filter_removed"] = e.filter()
             t["filter_ms"] = 1000.0 * (time.perf_counter() - tf)
+            c["filter_stats"] = e.filter_stats()
         e.update_threshold()
         if rank == 0:
             log(f"iter {it} (nccThreshold {thr[0]:.2f}, m_depth {thr[2]}): {time.perf_counter() - ts:.3f} s, patches {c['patches']}, candidates {c['candidates']}, "
@@ -245,6 +246,7 @@ def main():
     sweep_ms = index_ms = commit_ms = exchange_ms = 0.0
     launches = exchange_bytes = local_view_evals = 0
     patches_by_iter = [0] * SCHEDULE_ITERS
+    fstats = {}
     pool_after_iter0 = None
     timed = 0.0
     for s in range(args.steps):
@@ -261,6 +263,8 @@ def main():
         sweep_ms += t["sweep_ms"]; index_ms += t["index_ms"]; commit_ms += t["commit_ms"]; launches += t["sweep_launches"]
         exchange_ms += t.get("exchange_ms", 0.0); exchange_bytes += t.get("exchange_bytes", 0)
         local_view_evals += c["view_evals"]
+        for k, v in c.get("filter_stats", {}).items():
+            fstats[k] = fstats.get(k, 0) + v
         if it == 0 and pool_after_iter0 is None and world == 1 and args.cpu_seconds > 0 and not args.filter:
             pool_after_iter0 = e.patches()  # for the CPU baseline's sample B (untimed: after the closing barrier)
     dt = timed
@@ -323,6 +327,26 @@ def main():
             if ex is not None:
                 out["roofline"]["rank"] = 0
                 out["exchange"] = {"ms": exchange_ms, "bytes_gathered_per_rank": exchange_bytes, "collective": exchange}
+        if fstats:
+            # Filter::run (filter.cpp:25-49) -- algorithmic bytes per DESIGN.md "Filter::run": what the two heavy stages have to
+            # read and write if every datum moves once
+            f = fstats
+            ex_bytes = f["exact_patches"] * (128 + 72) + f["exact_view_evals"] * (5 * (8 + 16) + ALG_BYTES_PER_VIEW_EVAL)
+            nb_bytes = f["neighbor_patches"] * 128 + f["neighbor_tasks"] * 8 + f["neighbor_entries"] * 4 + f["neighbor_visited"] * 48 + f["neighbor_accepted"] * 32
+
+            def blk(ms, nbytes, units, unit_name):
+                gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms": ms,
+                        "algorithmic_bytes": nbytes, unit_name: units, "calls": args.steps}
+
+            out["roofline_filter"] = {
+                "filterExact": blk(f["exact_ms"], ex_bytes, f["exact_patches"], "patches"),
+                "filterNeighbor": blk(f["neighbor_ms"], nb_bytes, f["neighbor_patches"], "patches"),
+                "stage_ms": {k: f[k] for k in ("outside_ms", "exact_ms", "neighbor_ms", "groups_ms", "rebuild_ms", "total_ms")},
+                "counts": {k: f[k] for k in ("patches_in", "exact_view_evals", "neighbor_tasks", "neighbor_entries", "neighbor_visited", "neighbor_accepted")},
+                "note": "per stage: HIP-event time of its kernel(s) summed over the timed steps; bytes = record (128 B) + per surviving view 5 depth-map cells "
+                        "(8 B) with the patch each names (16 B) + 588 B of setRefImage samples + 72 B of lists written (filterExact); record + 8 B per "
+                        "list opened + 4 B per id walked + 48 B per distinct patch met + 32 B per neighbour fitted (filterNeighbor)"}
         if world == 1 and args.cpu_seconds > 0:
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(args, sc, seeds, pool_after_iter0, patches_by_iter if patches_by_iter[0] else [1, 0, 0])

@@ -143,6 +143,22 @@ int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out);
  * depth-map / m_vimages rebuilds in between; removed4 = patches removed by each of the four.  filterSmallGroups
  * groups by connected components of the symmetrised neighbour relation. */
 int mvs_engine_filter(mvs_engine* e, int64_t* removed4);
+/* what the last mvs_engine_filter did: HIP-event time of each stage's kernel(s) and the work counts behind the
+ * algorithmic-bytes model of DESIGN.md ("Filter::run"). */
+typedef struct mvs_filter_stats {
+    float outside_ms, exact_ms, neighbor_ms, groups_ms; /* the four filters */
+    float rebuild_ms;                                   /* the five setDepthMapsVGridsVPGridsAddPatchV rebuilds together */
+    float total_ms;
+    int64_t patches_in;          /* alive patches when Filter::run started */
+    int64_t exact_patches;       /* alive patches filterExact looked at */
+    int64_t exact_view_evals;    /* getTex calls of its setRefImage (588 algorithmic bytes each) */
+    int64_t neighbor_patches;    /* alive patches filterNeighbor looked at */
+    int64_t neighbor_tasks;      /* (view, cell) lists opened by findNeighbors: 25 cells x m_images, two grids each */
+    int64_t neighbor_entries;    /* list entries walked (4-byte ids) */
+    int64_t neighbor_visited;    /* distinct patches met: one 48-byte geometry gather each */
+    int64_t neighbor_accepted;   /* neighbours handed to filterQuad */
+} mvs_filter_stats;
+int mvs_engine_filter_stats(mvs_engine* e, mvs_filter_stats* out);
 
 /* The same split for view-sharded runs: every rank holds the whole pool, sweeps its own views
  * (view_begin/view_stride) and exchanges what it created before every rank commits the union. */

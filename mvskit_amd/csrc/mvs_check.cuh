@@ -177,8 +177,10 @@ DEV bool set_insert(int* table, unsigned mask, int k) {
     }
     return false;
 }
+// stats (Filter::filterNeighbor only): [0] lists opened, [1] entries walked, [2] distinct patches met, [3] neighbours
 template <int HCAP>
-DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin) {
+DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin,
+                       unsigned* stats = nullptr) {
     const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
     // Propagate::computeRadius, propagate.cpp:474-481: the second smallest unit
     float u = __int_as_float(0x7f800000);
@@ -212,6 +214,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     const int side = 2 * margin + 1, per = side * side;
     const int ntask = c.nimg * per;
     bool full = false;
+    unsigned n_entries = 0;
     for (int t0 = 0; t0 < ntask; t0 += 64) {
         const int t = t0 + wc.lane;
         const int i = min(t / per, c.nimg - 1), r = t % per;
@@ -223,6 +226,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
                 const int cell = yt * vw->gw + xt;
                 for (int kind = 0; kind < 2; ++kind) {
                     const ListRef l = cell_span(prm, cx, kind, v, cell);
+                    n_entries += (unsigned)l.n;
                     for (int j0 = 0; j0 < l.n; j0 += 4) {
                         int id[4];
 #pragma unroll
@@ -272,6 +276,10 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     if (cx.st) { cx.st[12] = cx.st[12] > (unsigned long long)visited ? cx.st[12] : (unsigned long long)visited; cx.st[13] = cx.st[13] > (unsigned long long)count ? cx.st[13] : (unsigned long long)count; }
 #endif
     if (visited > HCAP - HCAP / 8) return -1;  // beyond 7/8 full the oracle's table-size rule picks the next size
+    if (stats) {
+        for (int d = 32; d >= 1; d >>= 1) n_entries += (unsigned)__shfl_xor((int)n_entries, d);
+        stats[0] = 2u * (unsigned)ntask; stats[1] = n_entries; stats[2] = (unsigned)visited; stats[3] = (unsigned)count;
+    }
     return count;
 }
 

@@ -159,6 +159,9 @@ struct mvs_engine {
     DevBuf<uint8_t> tmp_bytes;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     mvs_timing timing{};
+    mvs_filter_stats fstats{};
+    DevBuf<unsigned long long> fstat_buf;  // [1024][4] partial sums of Filter::filterNeighbor's work counts
+    hipEvent_t fev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // multi-GPU (mvs_engine_comm_*): one RCCL communicator over the engines of the job
     ncclComm_t comm = nullptr;
     bool comm_owned = false;
@@ -443,6 +446,7 @@ int mvs_engine_create(const mvs_config* cfg, mvs_engine** out) {
     hipError_t he = hipStreamCreate(&e->stream);
     if (he != hipSuccess) { g_err = std::string("hipStreamCreate: ") + hipGetErrorString(he); delete e; return MVS_ERR_HIP; }
     for (auto& ev : e->ev) (void)hipEventCreate(&ev);
+    for (auto& ev : e->fev) (void)hipEventCreate(&ev);
     if (e->misc.ensure(8) || e->counters.ensure(1) || e->error_flag.ensure(1)) { delete e; return MVS_ERR_HIP; }
     (void)hipMemset(e->misc.p, 0, 8 * sizeof(unsigned long long));
     (void)hipMemset(e->error_flag.p, 0, sizeof(int32_t));
@@ -465,6 +469,8 @@ int mvs_engine_destroy(mvs_engine* e) {
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
     e->tmp_rec_in.release(); e->tmp_rec_out.release(); e->tmp_f_in.release(); e->tmp_f_out.release(); e->tmp_i.release(); e->tmp_bytes.release();
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->fev) if (ev) (void)hipEventDestroy(ev);
+    e->fstat_buf.release();
     (void)hipStreamDestroy(e->stream);
     delete e;
     return MVS_OK;
@@ -934,11 +940,19 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     HIPCHK(hipEventRecord(e->ev[0], st));
     HIPCHK(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
     if (e->pool_n > 0) HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));
+    e->fstats = mvs_filter_stats{};
+    if (int r = e->fstat_buf.ensure(4096)) return r;
+    HIPCHK(hipMemsetAsync(e->fstat_buf.p, 0, 4096 * sizeof(unsigned long long), st));
+    if (int r = mvs_engine_num_patches(e, &e->fstats.patches_in)) return r;
     if (int r = filter_rebuild(e, 0)) return r;
+    HIPCHK(hipEventRecord(e->fev[0], st));
     mvsk_filter_outside(current_params(e), e->kill.p, st);                       // filterOutside
+    HIPCHK(hipEventRecord(e->fev[1], st));
     if (int r = apply_kills(e, &rem[0])) return r;
     if (int r = filter_rebuild(e, 1)) return r;
+    e->fstats.exact_patches = e->fstats.patches_in - rem[0];
     HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
+    HIPCHK(hipEventRecord(e->fev[2], st));
 #ifdef MVS_STAGE_TIMING
     HIPCHK(hipMemsetAsync(e->counters.p, 0, sizeof(DCounters), st));
     mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, e->counters.p->stage, st);
@@ -954,17 +968,27 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
 #else
     mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, nullptr, st);          // filterExact
 #endif
+    HIPCHK(hipEventRecord(e->fev[3], st));
+    {
+        unsigned long long ev2[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(ev2, e->misc.p + 1, sizeof ev2, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        e->fstats.exact_view_evals = (int64_t)ev2[1];
+    }
     if (int r = apply_kills(e, &rem[1])) return r;
     if (int r = filter_rebuild(e, 1)) return r;
+    e->fstats.neighbor_patches = e->fstats.exact_patches - rem[1];
     {                                                                              // filterNeighbor(1)
         if (e->uf_parent.ensure(e->pool.cap)) return MVS_ERR_HIP;                  // reused as the retry list
         HIPCHK(hipMemsetAsync(e->misc.p + 4, 0, sizeof(unsigned long long), st));
         int32_t* nretry = reinterpret_cast<int32_t*>(e->misc.p + 4);
-        mvsk_filter_neighbor(current_params(e), e->kill.p, e->uf_parent.p, nretry, e->error_flag.p, st);
+        HIPCHK(hipEventRecord(e->fev[4], st));
+        mvsk_filter_neighbor(current_params(e), e->kill.p, e->uf_parent.p, nretry, e->error_flag.p, e->fstat_buf.p, st);
         int32_t nr = 0;
         HIPCHK(hipMemcpyAsync(&nr, nretry, sizeof nr, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        mvsk_filter_neighbor_retry(current_params(e), e->kill.p, e->uf_parent.p, nr, e->error_flag.p, st);
+        mvsk_filter_neighbor_retry(current_params(e), e->kill.p, e->uf_parent.p, nr, e->error_flag.p, e->fstat_buf.p, st);
+        HIPCHK(hipEventRecord(e->fev[5], st));
     }
     if (int r = apply_kills(e, &rem[2])) return r;
     if (int r = filter_rebuild(e, 1)) return r;
@@ -973,7 +997,9 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         if (int r = mvs_engine_num_patches(e, &alive)) return r;
         if (e->uf_parent.ensure(e->pool.cap) || e->uf_size.ensure(e->pool.cap)) return MVS_ERR_HIP;
         const int threshold = (int)std::max<int64_t>(20, alive / 10000);
+        HIPCHK(hipEventRecord(e->fev[6], st));
         mvsk_groups(current_params(e), e->uf_parent.p, e->uf_size.p, threshold, e->kill.p, st);
+        HIPCHK(hipEventRecord(e->fev[7], st));
         if (int r = apply_kills(e, &rem[3])) return r;
     }
     if (int r = filter_rebuild(e, 1)) return r;
@@ -988,8 +1014,28 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     e->timing = mvs_timing{};
     e->timing.index_ms = ms;  // whole Filter::run
     e->index_valid = false;
+    {
+        mvs_filter_stats& f = e->fstats;
+        f.total_ms = ms;
+        (void)hipEventElapsedTime(&f.outside_ms, e->fev[0], e->fev[1]);
+        (void)hipEventElapsedTime(&f.exact_ms, e->fev[2], e->fev[3]);
+        (void)hipEventElapsedTime(&f.neighbor_ms, e->fev[4], e->fev[5]);
+        (void)hipEventElapsedTime(&f.groups_ms, e->fev[6], e->fev[7]);
+        f.rebuild_ms = f.total_ms - f.outside_ms - f.exact_ms - f.neighbor_ms - f.groups_ms;  // rebuilds + the scans between the stages
+        std::vector<unsigned long long> part(4096);
+        HIPCHK(hipMemcpy(part.data(), e->fstat_buf.p, part.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long sum4[4] = {0, 0, 0, 0};
+        for (int b = 0; b < 1024; ++b) for (int k = 0; k < 4; ++k) sum4[k] += part[4 * b + k];
+        f.neighbor_tasks = (int64_t)sum4[0]; f.neighbor_entries = (int64_t)sum4[1]; f.neighbor_visited = (int64_t)sum4[2]; f.neighbor_accepted = (int64_t)sum4[3];
+    }
     if (removed4) for (int k = 0; k < 4; ++k) removed4[k] = rem[k];
     if (herr & 4) { g_err = "mvs_engine_filter: more than 14336 patches around one patch, or more than 4096 neighbours (engine limit)"; return MVS_ERR_CAPACITY; }
+    return MVS_OK;
+}
+
+int mvs_engine_filter_stats(mvs_engine* e, mvs_filter_stats* out) {
+    if (!e || !out) return MVS_ERR_ARG;
+    *out = e->fstats;
     return MVS_OK;
 }
 

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
 // does not fit is appended to `retry`.  Second launch: only those patches, with the large configuration.
 template <int HCAP, int RCAP>
 __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* retry, int32_t* nretry,
-                                                        int32_t* overflow) {
+                                                        int32_t* overflow, unsigned long long* stats /* [1024][4], spread over blocks */) {
     extern __shared__ float s_lds[];
     __shared__ int s_dummy[1];
     const int64_t id = todo ? (blockIdx.x < (unsigned)ntodo ? todo[blockIdx.x] : -1) : (int64_t)blockIdx.x;
@@ -705,7 +705,8 @@ __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* ki
     set_grids(prm, wc, c);
     const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, nullptr};
     int* table = reinterpret_cast<int*>(s_lds);
-    const int n = find_neighbors<HCAP>(prm, wc, cx, c, table, 4.0f, 2);
+    unsigned st4[4] = {0u, 0u, 0u, 0u};
+    const int n = find_neighbors<HCAP>(prm, wc, cx, c, table, 4.0f, 2, st4);
     if (n < 0 || n > RCAP) {
         if (wc.lane == 0) {
             if (retry) retry[atomicAdd(nretry, 1)] = (int32_t)id;
@@ -713,6 +714,7 @@ __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* ki
         }
         return;
     }
+    if (wc.lane < 4) atomicAdd(stats + 4 * (blockIdx.x & 1023u) + wc.lane, (unsigned long long)(wc.lane == 0 ? st4[0] : wc.lane == 1 ? st4[1] : wc.lane == 2 ? st4[2] : st4[3]));
     const bool reject = n < 6 || filter_quad(prm, wc, cx, c, table, n, s_lds + rows_offset(n)) != 0;
     if (wc.lane == 0 && reject) kill[id] = 1;
 }
@@ -932,15 +934,15 @@ void mvsk_filter_outside(const DParams& prm, uint8_t* kill, hipStream_t st) {
 void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)((prm.pool_n + MVS_FE_PATCHES - 1) / MVS_FE_PATCHES)), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals, stage);
 }
-void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, hipStream_t st) {
+void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, hipStream_t st) {
     if (prm.pool_n <= 0) return;
     hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP>), dim3((unsigned)prm.pool_n), dim3(64),
-                       (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow);
+                       (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow, stats);
 }
-void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* overflow, hipStream_t st) {
+void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* overflow, unsigned long long* stats, hipStream_t st) {
     if (ntodo <= 0) return;
     hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP>), dim3((unsigned)ntodo), dim3(64),
-                       (size_t)MVS_SET_LDS_FLOATS(MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP) * sizeof(float), st, prm, kill, todo, ntodo, (int32_t*)nullptr, (int32_t*)nullptr, overflow);
+                       (size_t)MVS_SET_LDS_FLOATS(MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP) * sizeof(float), st, prm, kill, todo, ntodo, (int32_t*)nullptr, (int32_t*)nullptr, overflow, stats);
 }
 void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st) {
     if (prm.pool_n <= 0) return;

@@ -22,7 +22,7 @@ EXPORTS = [
     "mvs_engine_pass", "mvs_engine_export_counts", "mvs_engine_export_device", "mvs_engine_commit_device",
     "mvs_engine_commit_local", "mvs_engine_depth_normal_map", "mvs_engine_probe", "mvs_engine_last_timing",
     "mvs_engine_filter", "mvs_comm_unique_id", "mvs_engine_comm_init", "mvs_engine_comm_attach", "mvs_engine_comm_release",
-    "mvs_engine_exchange", "mvs_list_cap",
+    "mvs_engine_exchange", "mvs_list_cap", "mvs_engine_filter_stats",
 ]
 
 
@@ -52,6 +52,12 @@ class Counters(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("index_ms", C.c_float), ("sweep_ms", C.c_float), ("commit_ms", C.c_float), ("sweep_launches", C.c_int32),
                 ("exchange_ms", C.c_float), ("exchange_bytes", C.c_int64)]
+
+
+class FilterStats(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("outside_ms", "exact_ms", "neighbor_ms", "groups_ms", "rebuild_ms", "total_ms")] + \
+               [(n, C.c_int64) for n in ("patches_in", "exact_patches", "exact_view_evals", "neighbor_patches", "neighbor_tasks", "neighbor_entries",
+                                         "neighbor_visited", "neighbor_accepted")]
 
 
 class EngineError(RuntimeError):
@@ -109,6 +115,7 @@ def load_library(cap32: bool = False):
     L.mvs_engine_comm_release.argtypes = [vp]
     L.mvs_engine_exchange.argtypes = [vp]
     L.mvs_list_cap.restype = C.c_int
+    L.mvs_engine_filter_stats.argtypes = [vp, C.POINTER(FilterStats)]
     _libs[LIB_PATH] = L
     return L
 
@@ -228,6 +235,11 @@ class Engine:
         r = np.zeros(4, dtype=np.int64)
         self._check(self.L.mvs_engine_filter(self.h, _ptr(r)))
         return {"outside": int(r[0]), "exact": int(r[1]), "neighbor": int(r[2]), "groups": int(r[3])}
+
+    def filter_stats(self):
+        f = FilterStats()
+        self._check(self.L.mvs_engine_filter_stats(self.h, C.byref(f)))
+        return {n: getattr(f, n) for n, _ in f._fields_}
 
     def engine_pass(self, it, p):
         c = Counters()
