@@ -86,12 +86,13 @@ DEV int is_neighbor_radius(const DParams& prm, const PGeo& l, const PGeo& r, flo
 
 // List of (kind, view, cell): kind 0 = m_pgrids, 1 = m_vpgrids.  Snapshot lists are contiguous CellEntry streams
 // (alive entries only); the destination cell being processed is read through its live id list instead.
-struct ListRef { const CellEntry* fat; int n; bool live; };
+struct ListRef { const CellEntry* fat; const int32_t* ids; int n; bool live; };
 DEV ListRef cell_span(const DParams& prm, const CheckCtx& cx, int kind, int view, int cell) {
-    if (kind == 0 && view == cx.live_view && cell == cx.live_cell) return {nullptr, cx.live_n, true};
+    if (kind == 0 && view == cx.live_view && cell == cx.live_cell) return {nullptr, nullptr, cx.live_n, true};
     const int g = (prm.views + view)->cell_base + cell;
-    if (kind == 0) return {prm.csr_fat + prm.csr_start[g], prm.csr_cnt[g], false};
-    return {prm.vcsr_fat + prm.vcsr_start[g], prm.vcsr_cnt[g], false};
+    if (kind == 0) { const int b = prm.csr_start[g]; return {prm.csr_fat + b, prm.csr_id32 + b, prm.csr_cnt[g], false}; }
+    const int b = prm.vcsr_start[g];
+    return {prm.vcsr_fat + b, prm.vcsr_id32 + b, prm.vcsr_cnt[g], false};
 }
 DEV PGeo entry_geo(const DParams& prm, const CheckCtx& cx, const ListRef& l, int j, int& id) {
     if (l.live) { id = cx.live_ids[j]; return load_geo(patch_ptr(prm, cx, id)); }
@@ -232,7 +233,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int j = min(j0 + q, l.n - 1);
-                            id[q] = l.live ? cx.live_ids[j] : l.fat[j].id;
+                            id[q] = l.live ? cx.live_ids[j] : l.ids[j];
                         }
 #pragma unroll
                         for (int q = 0; q < 4; ++q)

@@ -137,6 +137,7 @@ struct mvs_engine {
     DevBuf<int32_t> cnt, start, cursor, vcnt, vstart, vcursor, scan_tmp;
     DevBuf<unsigned long long> ids, vids;  // list entries of the index build: (descending ncc, id) sort keys
     DevBuf<CellEntry> fat, vfat;
+    DevBuf<int32_t> id32, vid32;  // the ids of fat / vfat alone
     DevBuf<int32_t> uf_parent, uf_size;  // Filter::filterSmallGroups union-find
     DevBuf<int32_t> cnt_alive, vcnt_alive;
     DevBuf<unsigned long long> dpgrid, best;
@@ -266,8 +267,8 @@ DParams current_params(mvs_engine* e) {
     p.pool = e->pool.p;
     p.pool_n = e->pool_n;
     p.total_cells = e->total_cells;
-    p.csr_start = e->start.p; p.csr_cnt = e->cnt_alive.p; p.csr_fat = e->fat.p;
-    p.vcsr_start = e->vstart.p; p.vcsr_cnt = e->vcnt_alive.p; p.vcsr_fat = e->vfat.p;
+    p.csr_start = e->start.p; p.csr_cnt = e->cnt_alive.p; p.csr_fat = e->fat.p; p.csr_id32 = e->id32.p;
+    p.vcsr_start = e->vstart.p; p.vcsr_cnt = e->vcnt_alive.p; p.vcsr_fat = e->vfat.p; p.vcsr_id32 = e->vid32.p;
     p.dpgrid = e->dpgrid.p;
     return p;
 }
@@ -285,6 +286,7 @@ int build_list(mvs_engine* e, bool vgrid, bool trim) {
     DevBuf<int32_t>& cursor = vgrid ? e->vcursor : e->cursor;
     DevBuf<unsigned long long>& ids = vgrid ? e->vids : e->ids;
     DevBuf<CellEntry>& fat = vgrid ? e->vfat : e->fat;
+    DevBuf<int32_t>& id32 = vgrid ? e->vid32 : e->id32;
     DevBuf<int32_t>& cnt_alive = vgrid ? e->vcnt_alive : e->cnt_alive;
     HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
     mvsk_index_count(p, vgrid ? nullptr : cnt.p, vgrid ? cnt.p : nullptr, st);
@@ -294,12 +296,13 @@ int build_list(mvs_engine* e, bool vgrid, bool trim) {
     HIPCHK(hipStreamSynchronize(st));
     if (int r = ids.ensure(tot + 16)) return r;
     if (int r = fat.ensure(tot + 16)) return r;
+    if (int r = id32.ensure(tot + 16)) return r;
     p = current_params(e);
     HIPCHK(hipMemsetAsync(cursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
     mvsk_index_fill(p, vgrid ? nullptr : start.p, vgrid ? nullptr : cursor.p, vgrid ? nullptr : ids.p, vgrid ? start.p : nullptr,
                     vgrid ? cursor.p : nullptr, vgrid ? ids.p : nullptr, st);
     mvsk_index_sort_trim(p, start.p, ids.p, trim ? 1 : 0, e->misc.p + 3, st);
-    mvsk_index_finalize(p, start.p, ids.p, fat.p, cnt_alive.p, st);
+    mvsk_index_finalize(p, start.p, ids.p, fat.p, id32.p, cnt_alive.p, st);
     return MVS_OK;
 }
 int build_depth(mvs_engine* e) {  // m_dpgrids from the alive pool
@@ -464,7 +467,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
     e->uf_parent.release(); e->uf_size.release();
-    e->vcursor.release(); e->vids.release(); e->fat.release(); e->vfat.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
+    e->vcursor.release(); e->vids.release(); e->fat.release(); e->vfat.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
     e->tmp_rec_in.release(); e->tmp_rec_out.release(); e->tmp_f_in.release(); e->tmp_f_out.release(); e->tmp_i.release(); e->tmp_bytes.release();

@@ -12,7 +12,7 @@ void mvsk_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tm
 void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, hipStream_t st);
 void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, unsigned long long* ids, const int32_t* vstart, int32_t* vcursor, unsigned long long* vids, hipStream_t st);
 void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st);
-void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* cnt_alive, hipStream_t st);
+void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* id32, int32_t* cnt_alive, hipStream_t st);
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, hipStream_t st);
 void mvsk_best_ncc_map(const DParams& prm, int view, unsigned long long* best, hipStream_t st);
 void mvsk_map_extract(const DParams& prm, int view, int kind, const unsigned long long* sel, float* depth, float* normal, int32_t* ids, int ncells, hipStream_t st);

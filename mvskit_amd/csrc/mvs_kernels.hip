@@ -188,7 +188,7 @@ __global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start
 }
 // After the trim: every list is compacted to its alive entries (order kept) and written out "fat".
 __global__ void k_index_finalize(DParams prm, const int32_t* __restrict__ start, const unsigned long long* __restrict__ ids, CellEntry* __restrict__ fat,
-                                 int32_t* __restrict__ cnt_alive) {
+                                 int32_t* __restrict__ id32, int32_t* __restrict__ cnt_alive) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= prm.total_cells) return;
     const int b = start[g], e = start[g + 1];
@@ -203,6 +203,7 @@ __global__ void k_index_finalize(DParams prm, const int32_t* __restrict__ start,
         ce.normal[0] = p->normal[0]; ce.normal[1] = p->normal[1]; ce.normal[2] = p->normal[2];
         ce.dscale = p->dscale; ce.ref = p->images[0]; ce.pad[0] = 0; ce.pad[1] = 0;
         fat[b + n] = ce;
+        id32[b + n] = id;
         ++n;
     }
     cnt_alive[g] = n;
@@ -871,8 +872,8 @@ void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, 
 void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
     hipLaunchKernelGGL(k_index_sort_trim, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, do_trim, trimmed);
 }
-void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* cnt_alive, hipStream_t st) {
-    hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, fat, cnt_alive);
+void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* id32, int32_t* cnt_alive, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, fat, id32, cnt_alive);
 }
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, hipStream_t st) {
     const int64_t n = prm.pool_n * prm.nviews;

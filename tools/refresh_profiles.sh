@@ -1,15 +1,21 @@
 #!/bin/bash
-# tools/refresh_profiles.sh: on a GPU box, regenerates what profiles/ holds for the current build
+# tools/refresh_profiles.sh [round]: on a GPU box, regenerates what profiles/ holds for the current build
 # (run through gpurun; copies land in gpurun_out/profiles_new/, to be moved into profiles/ after review)
 set -e
+R=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1"
-echo "== bench (with CPU baseline)"; timeout -k 10 500 $B > $out/bench_1gpu.json 2> $out/bench_1gpu.log
+echo "== bench (with CPU baseline)"; timeout -k 10 500 $B > $out/${R}_bench_1gpu.json 2> $out/${R}_bench_1gpu.log
 echo "== kernel trace"; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $B --cpu-seconds 0 > $out/kt.log 2>&1
 echo "== pmc fetch"; timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- $B --cpu-seconds 0 > $out/fetch.log 2>&1
 echo "== pmc write"; timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- $B --cpu-seconds 0 > $out/write.log 2>&1
-echo "== bench --filter"; timeout -k 10 500 $B --filter --cpu-seconds 0 > $out/bench_filter.json 2> $out/bench_filter.log
+echo "== pmc sq"; timeout -k 10 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/sq -o sq -- $B --cpu-seconds 0 > $out/sq.log 2>&1
+echo "== bench --filter"; timeout -k 10 500 $B --filter --cpu-seconds 0 > $out/${R}_bench_filter.json 2> $out/${R}_bench_filter.log
 echo "== kernel trace --filter"; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktf -o ktf -- $B --filter --cpu-seconds 0 > $out/ktf.log 2>&1
-find $out -name "*.csv" | head -20
+echo "== pmc fetch --filter"; timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetchf -o fetchf -- $B --filter --cpu-seconds 0 > $out/fetchf.log 2>&1
+echo "== pmc write --filter"; timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/writef -o writef -- $B --filter --cpu-seconds 0 > $out/writef.log 2>&1
+cd $GRAFT_REPO_ROOT
+python3 tools/pmc_sq.py $(find $out/sq -name "*counter_collection.csv" | head -1) > $out/${R}_pmc_sq_k_sweep.json
+find $out -name "*.csv" | head -30
