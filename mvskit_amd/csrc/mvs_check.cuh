@@ -179,6 +179,16 @@ DEV bool set_insert(int* table, unsigned mask, int k) {
     return false;
 }
 // stats (Filter::filterNeighbor only): [0] lists opened, [1] entries walked, [2] distinct patches met, [3] neighbours
+// the probe sequence of set_insert from slot p on (the key has already lost or given up its first slot)
+DEV bool set_insert_from(int* table, unsigned mask, int k, unsigned p) {
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        const int old = atomicMax(&table[p], k);
+        if (old == k || old == MVS_SET_EMPTY) return true;
+        if (old < k) k = old;
+        p = (p + 1) & mask;
+    }
+    return false;
+}
 template <int HCAP>
 DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin,
                        unsigned* stats = nullptr) {
@@ -235,9 +245,22 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
                             const int j = min(j0 + q, l.n - 1);
                             id[q] = l.live ? cx.live_ids[j] : l.ids[j];
                         }
+                        // first probe of the four keys together (four LDS atomics in flight): most keys are duplicates of
+                        // one already in the set or find their slot empty, and are done here; the rest walk on one by one.
+                        // The final layout does not depend on the order of the insertions.
+                        unsigned slot[4];
+                        int old[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (j0 + q < l.n && !set_insert(table, HCAP - 1, id[q])) full = true;
+                        for (int q = 0; q < 4; ++q) {
+                            slot[q] = mix32((uint32_t)id[q]) & (HCAP - 1);
+                            old[q] = (j0 + q < l.n) ? atomicMax(&table[slot[q]], id[q]) : id[q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (old[q] == id[q] || old[q] == MVS_SET_EMPTY) continue;
+                            const int carry = old[q] < id[q] ? old[q] : id[q];  // took the slot of a smaller key: carry that one on
+                            if (!set_insert_from(table, HCAP - 1, carry, (slot[q] + 1) & (HCAP - 1))) full = true;
+                        }
                     }
                 }
             }
@@ -249,11 +272,16 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     // ---- phase B: the visited ids to the front of the table (slot order kept), then record gather + predicate over
     // that dense list, the next 64 records in flight while the current ones are tested
     int visited = 0;
-    for (int k = 0; k < HCAP / 64; ++k) {
-        const int v = table[k * 64 + wc.lane];
-        const unsigned long long m = ballot(v >= 0);
-        if (v >= 0) table[visited + __popcll(m & ((1ull << wc.lane) - 1ull))] = v;  // visited + rank <= 64 k + lane: already read
-        visited += (int)__popcll(m);
+    for (int k = 0; k < HCAP / 64; k += 4) {  // four chunks of 64 slots per step: their reads are in flight together
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = table[(k + u) * 64 + wc.lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long m = ballot(v[u] >= 0);
+            if (v[u] >= 0) table[visited + __popcll(m & ((1ull << wc.lane) - 1ull))] = v[u];  // visited + rank <= 64 (k + u) + lane: already read
+            visited += (int)__popcll(m);
+        }
     }
     __syncthreads();
     int count = 0;
