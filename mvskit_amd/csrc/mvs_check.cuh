@@ -404,36 +404,50 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
         const int idx = lc == 5 ? 15 + lr : i * 5 - (i * (i - 1)) / 2 + (j - i);
         m = sums[idx];
     }
+    // Rows are not moved when a pivot is chosen: perm[r] names the lane row that holds logical row r (the row exchange of the
+    // oracle's solve5 becomes an exchange of two entries of perm), and the pivot's value comes out of the search itself.  Two
+    // ds_bpermute round trips per column (the column for the search; the multiplier and the pivot row for the update) and one
+    // for the whole back substitution.
     double x[5] = {0, 0, 0, 0, 0};
     bool solved = true;
+    int perm[5] = {0, 1, 2, 3, 4};
+    unsigned done = 0u;  // lane rows already used as pivot rows
 #pragma unroll
     for (int col = 0; col < 5; ++col) {
+        double cv[5];
+#pragma unroll
+        for (int r = col; r < 5; ++r) cv[r] = shfl_f64(m, perm[r] * 6 + col);
         int piv = col;
-        double best = fabs(shfl_f64(m, col * 6 + col));
+        double pv = cv[col], best = fabs(cv[col]);
 #pragma unroll
         for (int r = col + 1; r < 5; ++r) {
-            const double av = fabs(shfl_f64(m, r * 6 + col));
-            if (av > best) { best = av; piv = r; }
+            const double av = fabs(cv[r]);
+            if (av > best) { best = av; piv = r; pv = cv[r]; }
         }
-        int src = wc.lane;
-        if (lr == col) src = piv * 6 + lc;
-        else if (lr == piv) src = col * 6 + lc;
-        m = shfl_f64(m, src);
-        const double pv = shfl_f64(m, col * 6 + col);
+#pragma unroll
+        for (int r = col + 1; r < 5; ++r) {
+            if (piv == r) { const int t = perm[col]; perm[col] = perm[r]; perm[r] = t; }
+        }
+        done |= 1u << perm[col];
         if (fabs(pv) < 1e-30) solved = false;
         if (solved) {
             const double f = shfl_f64(m, lr * 6 + col) / pv;
-            const double pc = shfl_f64(m, col * 6 + lc);
-            if (lr > col && lc >= col) m -= f * pc;
+            const double pc = shfl_f64(m, perm[col] * 6 + lc);
+            if (!((done >> lr) & 1u) && lc >= col) m -= f * pc;
         }
     }
     if (solved) {
+        double mr[5][6];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int k = r; k < 6; ++k) mr[r][k] = shfl_f64(m, perm[r] * 6 + k);
 #pragma unroll
         for (int r = 4; r >= 0; --r) {
-            double a2 = shfl_f64(m, r * 6 + 5);
+            double a2 = mr[r][5];
 #pragma unroll
-            for (int k = r + 1; k < 5; ++k) a2 -= shfl_f64(m, r * 6 + k) * x[k];
-            x[r] = a2 / shfl_f64(m, r * 6 + r);
+            for (int k = r + 1; k < 5; ++k) a2 -= mr[r][k] * x[k];
+            x[r] = a2 / mr[r][r];
         }
     }
     const float x0 = solved ? (float)x[0] : 0.0f, x1 = solved ? (float)x[1] : 0.0f, x2 = solved ? (float)x[2] : 0.0f,

@@ -412,6 +412,7 @@ DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int
 #endif
 #define MVS_PIVOT_LDS4 144                         // float4 index of the per-view pivot colours (refinePatch, class lanes)
 #define MVS_FRAME_LDS_BYTES (48 * 48 + 16 * 16)    // frame lanes 0..47, 12 dwords each, + 16 pivots; the start of the kernel's dynamic LDS
+#define MVS_FRAME1_LDS_BYTES (48 * (MVS_LISTCAP > 16 ? MVS_LISTCAP : 16))  // what a single-proposal evaluation publishes there
 extern __shared__ float4 mvs_dyn_lds4[];
 DEV void frames_publish(const WaveCtx& wc, const Frame& f, int nlanes) {
     __syncthreads();  // whatever used the region before (setRefImage textures, Optim::check rows) is done
@@ -494,8 +495,12 @@ DEV float inv_msd(const DParams& prm, float ssd) {
 // loads of the next step are issued before the current step is reduced.
 // PIV (single proposal only): piv[0..2] receive, in view lane k, the channel means of view k (128 for a view that was
 // not sampled) -- the pivots of the class-lane evaluations that follow in refinePatch.
+// texs != nullptr (single proposal only): the centred texture of view k goes to LDS, texs[(3 k + channel) * tstride + sample],
+// and *ssd_out receives, in view lane k, its sum of squares -- what Optim::setRefImage needs of these very views when it
+// follows (postProcess), so that it does not sample them a second time.
 template <int NP, int U, bool PIV = false>
-DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[NP], float& incc_l, float* piv = nullptr) {
+DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[NP], float& incc_l, float* piv = nullptr,
+                   float* texs = nullptr, int tstride = 0, float* ssd_out = nullptr) {
     constexpr int NS = NP * U;
     static_assert(!PIV || NP == 1, "pivots come from a single-proposal evaluation");
     float d0[NP][3];
@@ -525,6 +530,9 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
         const float s = ssd_sum(d0[g][0], d0[g][1], d0[g][2]);
         okv[g] |= (unsigned)pr[g].ok;
         if (wc.lane == 16 * g) ssd_l = s;
+        if (NP == 1 && texs && wc.sample_lane) {
+            texs[0 * tstride + wc.lane] = d0[g][0]; texs[1 * tstride + wc.lane] = d0[g][1]; texs[2 * tstride + wc.lane] = d0[g][2];
+        }
     }
     for (int k0 = 1; k0 < n; k0 += U) {
         Pending p[NS];
@@ -555,6 +563,9 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
                 if (k < n) {
                     okv[g] |= (unsigned)p[g * U + u].ok << k;
                     if (wc.lane == 16 * g + k) { ssd_l = s; dot_l = dt; }
+                    if (NP == 1 && texs && wc.sample_lane) {
+                        texs[(3 * k + 0) * tstride + wc.lane] = e0; texs[(3 * k + 1) * tstride + wc.lane] = e1; texs[(3 * k + 2) * tstride + wc.lane] = e2;
+                    }
                 }
             }
     }
@@ -565,6 +576,7 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
     for (int g = 0; g < NP; ++g) okm[g] = (unsigned)rfl((int)okv[g]);
 #pragma unroll
     for (int g = 0; g < NP; ++g) wc.view_evals += (okm[g] & 1u) ? (unsigned)__popc(okm[g]) : 0u;
+    if (NP == 1 && ssd_out) *ssd_out = ssd_l;
     const float inv_l = inv_msd(prm, ssd_l);
     float inv0_l = rlf(inv_l, 0);
     if (NP > 1) {
@@ -816,7 +828,8 @@ DEV float compute_ncc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int 
 }
 
 // Optim::setINCCs (vector), optim.cpp:708-746: returns the view-lane INCC array (reference vs every view)
-DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n, int robust, unsigned* okm_out = nullptr) {
+DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n, int robust, unsigned* okm_out = nullptr,
+                    float* texs = nullptr, int tstride = 0, float* ssd_out = nullptr) {
     const int ref = rli(img, 0);
     F4 px, py;
     get_paxes(prm, prm.views + ref, coord, normal, px, py);
@@ -824,7 +837,7 @@ DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int im
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < n);
     unsigned okm[1];
     float incc_l;
-    eval_core<1, MVS_U1>(prm, wc, f, n, okm, incc_l);
+    eval_core<1, MVS_U1>(prm, wc, f, n, okm, incc_l, nullptr, texs, tstride, ssd_out);
     if (okm_out) *okm_out = okm[0];
     if (!(okm[0] & 1u)) return 2.0f;
     float incc = robust ? robustincc(incc_l) : incc_l;
@@ -874,11 +887,26 @@ DEV void add_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c
 // keep_n > 0 (first constraintImages of postProcess inside the sweep): refinePatch left the final m_ncc to this
 // evaluation -- computeINCC at the refined patch samples the first min(tau, keep_n) of these very textures -- so it is
 // taken here, as the tail of computeINCC over the robust INCCs of those views with the weights refinePatch computed.
-DEV void constraint_images(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c, float nccThreshold, float keep_w = 0.0f, int keep_n = 0) {
+// Kept textures of an evaluation (postProcess: constraintImages hands them to setRefImage): where they lie in LDS, the sum
+// of squares of each (view lanes, indexed like the list at the time of the evaluation), which views sampled, and for every
+// entry of the list as it is NOW the index it had then (the list is compacted in between).
+struct KeptTex {
+    float* texs; int tstride;
+    float ssd;       // view lanes (old index)
+    unsigned okm;    // bit k: old view k sampled
+    int orig;        // view lanes (current index) -> old index
+};
+DEV void constraint_images(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c, float nccThreshold, float keep_w = 0.0f, int keep_n = 0,
+                           KeptTex* kt = nullptr) {
     unsigned okm = 0u;
-    const float inccs = set_inccs(prm, wc, c.coord, c.normal, c.img, c.nimg, 0, &okm);
+    float ssd = 1.0f;
+    const float inccs = set_inccs(prm, wc, c.coord, c.normal, c.img, c.nimg, 0, &okm, kt ? kt->texs : nullptr, kt ? kt->tstride : 0, kt ? &ssd : nullptr);
     if (keep_n > 0) c.ncc = 1.0f - unrobustincc(weighted_incc(prm, okm, robustincc(inccs), keep_w, keep_n));
     const bool keep = wc.lane == 0 || (wc.lane < c.nimg && inccs < 1.0f - nccThreshold);
+    if (kt) {
+        kt->ssd = ssd; kt->okm = okm; kt->orig = wc.lane;
+        (void)compact1(scratch, wc, keep, kt->orig);
+    }
     c.nimg = compact1(scratch, wc, keep, c.img);
 }
 
@@ -1128,7 +1156,7 @@ STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, u
 
 // ------------------------------------------------------------------ post-processing
 // Optim::filterImagesByAngle, optim.cpp:325-346
-DEV void filter_images_by_angle(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c) {
+DEV void filter_images_by_angle(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c, KeptTex* kt = nullptr) {
     bool bad = false;
     if (wc.lane < c.nimg) {
         const F4 ray = nrm4(sub4(ld4((prm.views + c.img)->center), c.coord));
@@ -1136,6 +1164,7 @@ DEV void filter_images_by_angle(const DParams& prm, const WaveCtx& wc, int* scra
     }
     const unsigned long long bm = ballot(bad);
     if (bm & 1ull) { c.nimg = 0; return; }
+    if (kt) (void)compact1(scratch, wc, wc.lane < c.nimg && !bad, kt->orig);
     c.nimg = compact1(scratch, wc, wc.lane < c.nimg && !bad, c.img);
 }
 DEV void set_grids(const DParams& prm, const WaveCtx& wc, Cand& c) {
@@ -1146,20 +1175,31 @@ DEV void set_grids(const DParams& prm, const WaveCtx& wc, Cand& c) {
 // texs: LDS [LISTCAP][3][tstride] centred textures.  The V(V-1)/2 pair products get one lane each and are summed
 // over the samples in the reference's sequential order (optim.cpp:605-607).
 DEV int pair_index(int a, int b, int n) { return a * (2 * n - a - 1) / 2 + (b - a - 1); }  // a < b < n
-DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride, Cand& c) {
+// kt != nullptr (postProcess): the centred textures of these views are in LDS already -- the constraintImages just before
+// sampled them at this very patch with this very reference view (engine schedule: they are not sampled a second time, the
+// work counters do not count a second evaluation); entry i of the list is entry kt->orig of that evaluation.
+DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride, Cand& c, const KeptTex* kt = nullptr) {
     if (c.nimg == 0) return;
     const int n = c.nimg;
     const int ref = rli(c.img, 0);
     WC_T0(wc)
+    unsigned okmask = 0;
+    float ssd_l = 1.0f;
+    int orig = wc.lane;  // where view i's texture lies
+    if (kt) {
+        texs = kt->texs;
+        orig = wc.lane < n ? kt->orig : 0;
+        ssd_l = __shfl(kt->ssd, orig);
+        okmask = (unsigned)ballot(wc.lane < n && ((kt->okm >> orig) & 1u));
+        __syncthreads();
+    } else {
     F4 px, py;
     get_paxes(prm, prm.views + ref, c.coord, c.normal, px, py);
     wc.evals++;
     const Frame f = make_frame(prm, c.coord, px, py, c.normal, c.img, wc.lane < n);
-    unsigned okmask = 0;
     WC_ADD(wc, 1)
     __syncthreads();
     // centred textures to LDS (three views in flight per step), their ssd to view lanes
-    float ssd_l = 1.0f;
     {
         Pending pn[3];
 #pragma unroll
@@ -1191,13 +1231,14 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
             }
         }
     }
+    }
     const float inv_l = inv_msd(prm, ssd_l);
     WC_ADD(wc, 2)
     __syncthreads();
     // one lane per pair (a, b), a < b < n: 120 pairs = 2 rounds of 64 lanes for 16 views (496 = 8 rounds for 32); the
     // robust INCC of pair q goes to LDS behind the textures
     const int npairs = n * (n - 1) / 2;
-    float* pairv = texs + MVS_LISTCAP * 3 * tstride;
+    float* pairv = texs + MVS_LISTCAP * 3 * tstride;  // behind the textures
     for (int r = 0; r * 64 < npairs; ++r) {
         const int q0 = wc.lane + 64 * r;
         int q = q0;
@@ -1205,8 +1246,8 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
         int a = 0;
         if (act) { while (q >= n - 1 - a) { q -= n - 1 - a; ++a; } }
         const int b = act ? a + 1 + q : 1;
-        const float* ta = texs + (a * 3) * tstride;
-        const float* tb = texs + (b * 3) * tstride;
+        const float* ta = texs + (__shfl(orig, a) * 3) * tstride;
+        const float* tb = texs + (__shfl(orig, b) * 3) * tstride;
         float acc = 0.0f;
         for (int i = 0; i < prm.wsz; ++i)
             acc += fma_(ta[2 * tstride + i], tb[2 * tstride + i], fma_(ta[tstride + i], tb[tstride + i], ta[i] * tb[i]));
@@ -1295,12 +1336,15 @@ STAGE int post_process(const DParams& prm, WaveCtx& wc, int* scratch, float* tex
     if (get_mask_all(prm, wc, c) == 0) return -1;
     const int keep_n = keep ? c.nimg : 0;
     add_images(prm, wc, scratch, c);
-    constraint_images(prm, wc, scratch, c, prm.nccThreshold, keep_w, keep_n);
-    filter_images_by_angle(prm, wc, scratch, c);
+    // the textures of this evaluation stay in LDS (behind the frame region, which the evaluation itself uses) for setRefImage
+    KeptTex kt;
+    kt.texs = texs + MVS_FRAME1_LDS_BYTES / 4; kt.tstride = tstride; kt.ssd = 1.0f; kt.okm = 0u; kt.orig = wc.lane;
+    constraint_images(prm, wc, scratch, c, prm.nccThreshold, keep_w, keep_n, &kt);
+    filter_images_by_angle(prm, wc, scratch, c, &kt);
     if (c.nimg < prm.minImageNum) return -1;
     set_grids(prm, wc, c);
     const int ref_before = rli(c.img, 0);
-    set_ref_image(prm, wc, texs, tstride, c);
+    set_ref_image(prm, wc, texs, tstride, c, &kt);
     // Same reference view as before: the second constraintImages would sample the very textures of the first one for
     // the views that passed it, under the same threshold, and remove nothing.  It runs when the reference changed.
     if (rli(c.img, 0) != ref_before) constraint_images(prm, wc, scratch, c, prm.nccThreshold);

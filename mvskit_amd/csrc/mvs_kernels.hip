@@ -890,7 +890,8 @@ void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st
 }
 size_t mvsk_sweep_lds_bytes(const DParams& prm) {
     // setRefImage: the centred textures of MVS_LISTCAP views (9408 B at wsize 7 and 16 views) + one value per view pair
-    const size_t texs = ((size_t)MVS_LISTCAP * 3 * prm.wsz + (size_t)MVS_LISTCAP * (MVS_LISTCAP - 1) / 2) * sizeof(float);
+    // in postProcess they lie behind the frame region (the evaluation that produces them publishes its frames there)
+    const size_t texs = MVS_FRAME1_LDS_BYTES + ((size_t)MVS_LISTCAP * 3 * prm.wsz + (size_t)MVS_LISTCAP * (MVS_LISTCAP - 1) / 2) * sizeof(float);
     const size_t chk = (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float);                      // Optim::check hash set + rows
     return texs > chk ? texs : chk;
 }

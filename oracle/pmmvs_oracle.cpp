@@ -1502,7 +1502,9 @@ int post_process(const Scene& s, Patch& p, const DestCtx* ctx, orc_counters* cnt
     if (p.nimg < s.cfg.minImageNum) return -1;
     set_grids(s, p);
     const int ref_before = p.img[0];
-    set_ref_image(s, p, cnt);
+    /* engine schedule: setRefImage works on the textures the constraintImages above has just sampled (same patch, same
+     * reference view, a subset of its views) -- the engine keeps them in LDS and does not sample or count them again */
+    set_ref_image(s, p, (s.cfg.schedule == ORC_SCHEDULE_ENGINE && !s.cfg.literal_evals) ? nullptr : cnt);
     /* engine schedule: with the reference view unchanged the second constraintImages would sample the very textures of
      * the first one for the views that passed it, under the same threshold, and remove nothing -- it is not run */
     if (s.cfg.schedule != ORC_SCHEDULE_ENGINE || s.cfg.literal_evals || p.img[0] != ref_before) constraint_images(s, p, s.nccThreshold, cnt);
