@@ -155,6 +155,11 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))  # nothing has touched the GPU in this process
 
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at communicator set-up, Gloo's
+    # connection notes): from here on file descriptor 1 is stderr, and the JSON line goes to a private copy of the real stdout.
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -351,7 +356,7 @@ def main():
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(args, sc, seeds, pool_after_iter0, patches_by_iter if patches_by_iter[0] else [1, 0, 0])
             out["cpu_baseline_all_cores"] = out["cpu_baseline"]["all_cores"]
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     e.close()
     if dist is not None:
         dist.destroy_process_group()
