@@ -246,13 +246,14 @@ def test_config4_48_views_4k_fits_one_gpu():
     p = e.patches()
     made = p[p["dscale"] > 0]
     assert 500_000 < made.shape[0] <= c["inserted"] + c["replaced"]
-    assert made["nimages"].min() >= CFG["minImageNum"] and made["nimages"].max() <= 16
-    k = np.arange(16)[None, :] < made["nimages"][:, None]
-    assert np.all(made["images"][:, :16][k] < n)
+    assert e.list_cap == 32  # more than 16 views: the 32-view build (libmvskit_engine_cap32.so)
+    assert made["nimages"].min() >= CFG["minImageNum"] and 16 < made["nimages"].max() <= 32
+    k = np.arange(32)[None, :] < made["nimages"][:, None]
+    assert np.all(made["images"][:, :32][k] < n)
     assert np.isfinite(made["coord"]).all() and np.all(made["ncc"] <= 1.0 + 1e-6)
     used = (free0 - free1) / 2 ** 30
     assert used < 288.0
-    rec = {"views": n, "width": W, "height": H, "cells": 48 * 1920 * 1080, "seeds": int(seeds.shape[0]), "max_patches": 48_000_000,
+    rec = {"views": n, "width": W, "height": H, "list_cap": e.list_cap, "cells": 48 * 1920 * 1080, "seeds": int(seeds.shape[0]), "max_patches": 48_000_000,
            "hbm_used_GiB_after_one_iteration": used, "hbm_total_GiB": total_mem / 2 ** 30, "patches": c["patches"], "view_evals": c["view_evals"],
            "timing_ms": t, "pool_alive": int(p.shape[0])}
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
