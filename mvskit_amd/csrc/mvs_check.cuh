@@ -168,17 +168,12 @@ DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
 //   phase B: the table is streamed 64 slots at a time: record gather (next chunk's loads in flight), predicate,
 //            ballot compaction of the accepted ids to the front of the table.
 #define MVS_SET_EMPTY (-1)
-DEV bool set_insert(int* table, unsigned mask, int k) {
-    unsigned p = mix32((uint32_t)k) & mask;
-    for (unsigned probe = 0; probe <= mask; ++probe) {
-        const int old = atomicMax(&table[p], k);
-        if (old == k || old == MVS_SET_EMPTY) return true;
-        if (old < k) k = old;  // took the slot of a smaller key: carry that one on
-        p = (p + 1) & mask;
-    }
-    return false;
+// home slot of an id: multiplicative (Fibonacci) hashing, the top log2(capacity) bits of id * 2^32 / phi -- one multiply and
+// a shift per list entry instead of the avalanche of mix32 (ids are dense small integers; the oracle's set_home is the same)
+template <int HCAP> DEV unsigned set_home(int k) {
+    static_assert((HCAP & (HCAP - 1)) == 0 && HCAP >= 64, "power of two");
+    return ((uint32_t)k * 0x9E3779B1u) >> (32 - __builtin_ctz((unsigned)HCAP));
 }
-// stats (Filter::filterNeighbor only): [0] lists opened, [1] entries walked, [2] distinct patches met, [3] neighbours
 // the probe sequence of set_insert from slot p on (the key has already lost or given up its first slot)
 DEV bool set_insert_from(int* table, unsigned mask, int k, unsigned p) {
     for (unsigned probe = 0; probe <= mask; ++probe) {
@@ -252,7 +247,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
                         int old[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            slot[q] = mix32((uint32_t)id[q]) & (HCAP - 1);
+                            slot[q] = set_home<HCAP>(id[q]);
                             old[q] = (j0 + q < l.n) ? atomicMax(&table[slot[q]], id[q]) : id[q];
                         }
 #pragma unroll

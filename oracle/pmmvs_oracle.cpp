@@ -1161,7 +1161,7 @@ void engine_neighbor_order(std::vector<int> visited, std::vector<int>& nb /* sor
     while (visited.size() * 8 > cap * 7) cap *= 2; /* beyond the engine's limits (it reports an error there) */
     std::vector<int> table(cap, -1);
     for (size_t k = visited.size(); k-- > 0;) {
-        size_t p = mix32((uint32_t)visited[k]) & (cap - 1);
+        size_t p = ((uint32_t)visited[k] * 0x9E3779B1u) >> (32 - __builtin_ctzll((unsigned long long)cap)); /* set_home: Fibonacci hashing */
         while (table[p] != -1) p = (p + 1) & (cap - 1);
         table[p] = visited[k];
     }
