@@ -228,8 +228,8 @@ static mvs_patch to_record(const Patch& p) {
     memset(&r, 0, sizeof r);
     for (int k = 0; k < 4; ++k) { r.coord[k] = p.m_coord[k]; r.normal[k] = p.m_normal[k]; }
     r.ncc = p.m_ncc; r.dscale = p.m_dscale; r.ascale = p.m_ascale; r.tmp = p.m_tmp;
-    r.nimages = std::min<int>((int)p.m_images.size(), MVS_LIST_CAP);
-    r.nvimages = std::min<int>((int)p.m_vimages.size(), MVS_LIST_CAP);
+    r.nimages = std::min<int>((int)p.m_images.size(), MVS_MAX_IMAGES);   // what a record stores; the engine cuts to its own list cap
+    r.nvimages = std::min<int>((int)p.m_vimages.size(), MVS_MAX_IMAGES);
     for (int i = 0; i < r.nimages; ++i) r.images[i] = (uint8_t)p.m_images[i];
     for (int i = 0; i < r.nvimages; ++i) r.vimages[i] = (uint8_t)p.m_vimages[i];
     r.flags = 1;
@@ -374,6 +374,38 @@ void Propagate::run(const int iter) {  // propagate.cpp:28-64: the drop-in bound
          << m_pcount + m_fcount1 << endl;
 }
 
+// ------------------------------------------------------------------ Optim / DepthNormInit
+int Optim::probe(int op, Patch& patch, float* value) {
+    if (m_pmmvps.m_status != 0) return -1;
+    (void)mvs_engine_set_thresholds(m_pmmvps.m_engine, m_pmmvps.m_nccThreshold, m_pmmvps.m_nccThresholdBefore, m_pmmvps.m_depth);
+    const mvs_patch in = to_record(patch);
+    mvs_patch out = in;
+    float f = 0.0f;
+    int32_t flag = 0;
+    const int r = mvs_engine_probe(m_pmmvps.m_engine, op, 1, &in, nullptr, &out, &f, &flag);
+    if (r != 0) { cerr << "Optim: " << mvs_last_error() << endl; m_pmmvps.m_status = r; return -1; }
+    if (op != MVS_PROBE_NCC) {
+        const Ppatch p = from_record(out);
+        const int id = patch.m_id;
+        patch = *p;
+        patch.m_id = id;
+    }
+    if (value) *value = f;
+    return flag;
+}
+int Optim::preProcess(Patch& patch) { return probe(MVS_PROBE_PREPROCESS, patch, nullptr); }
+void Optim::refinePatch(Patch& patch, const int) { (void)probe(MVS_PROBE_REFINE, patch, nullptr); }
+int Optim::postProcess(Patch& patch) { return probe(MVS_PROBE_POSTPROCESS, patch, nullptr); }
+float Optim::computeNcc(const Patch& patch) {
+    Patch p = patch;
+    float v = -1.0f;
+    (void)probe(MVS_PROBE_NCC, p, &v);
+    return v;
+}
+void DepthNormInit::createPatches() {  // depth_normal_init.cpp:29-33 (isTest)
+    if (m_pmmvps.m_patchManager.readPatches() != 0) cerr << "DepthNormInit::createPatches: no ply/00000000.patch under " << m_pmmvps.m_prefix << endl;
+}
+
 // ------------------------------------------------------------------ Filter
 void Filter::run() {  // filter.cpp:25-49
     int64_t r4[4] = {0, 0, 0, 0};
@@ -386,7 +418,7 @@ void Filter::run() {  // filter.cpp:25-49
 }
 
 // ------------------------------------------------------------------ PmMvps
-PmMvps::PmMvps() : m_patchManager(*this), m_propagate(*this), m_filter(*this) {}
+PmMvps::PmMvps() : m_dnInit(*this), m_patchManager(*this), m_propagate(*this), m_optim(*this), m_filter(*this) {}
 PmMvps::~PmMvps() { if (m_engine) mvs_engine_destroy(m_engine); }
 
 int PmMvps::createEngine(float maxAngle, float quad) {
@@ -461,7 +493,9 @@ void PmMvps::init(const Option& option, const PhotoSet& photos) {  // pmmvps.cpp
     m_quadThreshold = option.m_quadThreshold;
     if (int r = createEngine(option.m_maxAngleThreshold, option.m_quadThreshold)) { m_status = r; return; }
     m_patchManager.init();
+    m_dnInit.init();
     m_propagate.init();
+    m_optim.init();
     m_filter.init();
 }
 void PmMvps::init(const Option& option) {
@@ -474,7 +508,7 @@ void PmMvps::updateThreshold() { m_nccThreshold -= 0.05f; m_nccThresholdBefore -
 
 void PmMvps::run() {  // pmmvps.cpp:76-114
     if (m_status != 0) return;
-    if (m_writeFiles) (void)m_patchManager.readPatches();  // DepthNormInit::createPatches, isTest branch (depth_normal_init.cpp:29-33)
+    if (m_writeFiles) m_dnInit.createPatches();  // pmmvps.cpp:83
     ++m_depth;
     for (int iter = 0; iter < ITER; ++iter) {
         cerr << "\n---------------------\nIteration: " << iter << "\n---------------------" << endl;
@@ -587,6 +621,33 @@ extern "C" int mvshost_patch_roundtrip(const char* text, char* out, int cap, mvs
     return (int)s.size();
 }
 // Camera text (camera.cpp:27-63): returns the 3x4 projection
+// Optim::preProcess -> refinePatch -> postProcess on each of n seeds through the mirror's Optim class (one patch per call);
+// flags[i] = -1 where a stage rejected the patch, ncc[i] = Optim::computeNcc of the seed
+extern "C" int mvshost_optim_chain(int nviews, int width, int height, const float* P, const unsigned char* rgb, int level, int csize, int wsize,
+                                   int minImageNum, float nccThreshold, unsigned seed, long long n, const mvs_patch* seeds, mvs_patch* out, int* flags, float* ncc) {
+    using namespace mvshost;
+    Option option;
+    option.m_nimages = nviews; option.m_nillums = 1; option.m_level = level; option.m_csize = csize; option.m_wsize = wsize;
+    option.m_minImageNum = minImageNum; option.m_nccThreshold = nccThreshold; option.m_flag = -1;
+    for (int i = 0; i < nviews; ++i) option.m_images.push_back(i);
+    PhotoSet ps;
+    ps.m_images = option.m_images;
+    for (int i = 0; i < nviews; ++i) { ps.m_dict[i] = i; ps.setPhoto(i, width, height, P + 12 * i, rgb + (size_t)i * width * height * 3, nullptr); }
+    PmMvps pmmvps;
+    pmmvps.m_seed = seed; pmmvps.m_writeFiles = false;
+    pmmvps.init(option, ps);
+    if (pmmvps.m_status) return pmmvps.m_status;
+    for (long long i = 0; i < n; ++i) {
+        Ppatch pp = from_record(seeds[i]);
+        ncc[i] = pmmvps.m_optim.computeNcc(*pp);
+        int f = pmmvps.m_optim.preProcess(*pp);
+        if (f == 0) { pmmvps.m_optim.refinePatch(*pp, 100); f = pmmvps.m_optim.postProcess(*pp); }
+        flags[i] = f;
+        out[i] = to_record(*pp);
+        if (pmmvps.m_status) return pmmvps.m_status;
+    }
+    return 0;
+}
 extern "C" int mvshost_pbm_probe(const char* mname, int width, int height, unsigned char* out) {
     mvshost::Photo ph;
     ph.m_width = width; ph.m_height = height;

@@ -131,6 +131,36 @@ protected:
     PmMvps& m_pmmvps;
 };
 
+// pmmvps/optim.hpp:24-112: the three calls Propagate::propagatePatch makes on a candidate (propagate.cpp:182-196), here on
+// one host-side Patch at a time through the engine's batched single-function entry (mvs_engine_probe).  Inside
+// Propagate::run they never cross the boundary -- the sweep kernel runs them on the device -- so this class is for callers
+// that drive Optim directly, as the reference's other propagation modes and its tests would.
+class Optim {
+public:
+    explicit Optim(PmMvps& pmmvps) : m_pmmvps(pmmvps) {}
+    void init() {}
+    int preProcess(Patch& patch);                    // optim.cpp:137-163; -1 = rejected
+    void refinePatch(Patch& patch, const int time);  // optim.cpp:470-547 (`time` is ignored there too, D12)
+    int postProcess(Patch& patch);                   // optim.cpp:260-298; -1 = rejected
+    float computeNcc(const Patch& patch);            // PatchManager::computeNcc -> Optim::computeINCC, patch_manager.cpp:401-404
+
+protected:
+    int probe(int op, Patch& patch, float* value);
+    PmMvps& m_pmmvps;
+};
+
+// pmmvps/depth_normal_init.hpp:20-44: the reference hard-wires isTest = 1 (depth_normal_init.cpp:30), i.e. the seeds are
+// PatchManager::readPatches() of ply/00000000.patch; the disabled depth-PLY + normal-PLY branch (:34-144) is not built.
+class DepthNormInit {
+public:
+    explicit DepthNormInit(PmMvps& pmmvps) : m_pmmvps(pmmvps) {}
+    void init() {}
+    void createPatches();
+
+protected:
+    PmMvps& m_pmmvps;
+};
+
 // pmmvps/filter.hpp:24-63
 class Filter {
 public:
@@ -178,8 +208,10 @@ public:
     float m_nccThresholdBefore = 0.4f, m_maxAngleThreshold = 0;
 
     PhotoSet m_photoSet;
+    DepthNormInit m_dnInit;
     PatchManager m_patchManager;
     Propagate m_propagate;
+    Optim m_optim;
     Filter m_filter;
     mvs_engine* m_engine = nullptr;  // Optim + the PatchManager grids live behind this handle
     unsigned m_seed = 1;

@@ -26,6 +26,8 @@ def host():
     L.mvshost_set_ranks.restype = None
     L.mvshost_set_filter.argtypes = [C.c_int]
     L.mvshost_set_filter.restype = None
+    L.mvshost_optim_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint,
+                                      C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mvshost_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint,
                               C.c_int, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
@@ -107,6 +109,41 @@ def test_pbm_mask(host, tmp_path):
     g = tmp_path / "ascii.pbm"
     g.write_bytes(b"P1\n2 2\n0 1 1 0\n")
     assert host.mvshost_pbm_probe(str(g).encode(), 2, 2, out.ctypes.data) == -1  # "Only accept binary pbm format"
+
+
+@pytest.mark.gpu
+def test_optim_class_of_the_mirror(host, small_multi_scene):
+    """The mirror's Optim (optim.hpp:24-112: preProcess / refinePatch / postProcess / computeNcc on one Patch) against the
+    same single functions driven through the ctypes binding, patch by patch: identical records and flags."""
+    sc = small_multi_scene
+    seeds = synth.make_seeds(sc, stride=12, seed=8)[:48]
+    n = seeds.shape[0]
+    P = np.ascontiguousarray(sc.P, dtype=np.float32)
+    img = np.ascontiguousarray(sc.images)
+    sd = np.ascontiguousarray(seeds)
+    out = np.zeros(n, dtype=engine.PATCH_DTYPE)
+    flags = np.zeros(n, np.int32)
+    ncc = np.zeros(n, np.float32)
+    assert host.mvshost_optim_chain(sc.nviews, sc.W, sc.H, P.ctypes.data, img.ctypes.data, 0, 2, 7, 3, C.c_float(0.7), 9, n, sd.ctypes.data,
+                                    out.ctypes.data, flags.ctypes.data, ncc.ctypes.data) == 0
+    e = engine.Engine(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, nccThreshold=0.7, seed=9, depth=0)
+    e.set_scene(sc)
+    passed = 0
+    for i in range(n):
+        one = np.ascontiguousarray(seeds[i:i + 1])
+        one["nvimages"] = 0
+        _, v, _ = e.probe(engine.PROBE_NCC, one)
+        assert v[0] == ncc[i]
+        rec, _, f = e.probe(engine.PROBE_PREPROCESS, one)
+        if f[0] == 0:
+            rec, _, _ = e.probe(engine.PROBE_REFINE, rec)
+            rec, _, f = e.probe(engine.PROBE_POSTPROCESS, rec)
+        assert f[0] == flags[i], i
+        for k in ("coord", "normal", "ncc", "dscale", "nimages", "images"):
+            np.testing.assert_array_equal(rec[k][0], out[k][i], err_msg=f"{k} of patch {i}")
+        passed += int(f[0] == 0)
+    assert passed > 10
+    e.close()
 
 
 @pytest.mark.gpu
