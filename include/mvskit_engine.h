@@ -77,7 +77,7 @@ typedef struct mvs_config {
     int32_t view_propagation;/* 1 = also run the view-propagation branch the reference keeps commented out (propagate.cpp:110-120) */
     int32_t shard_index;     /* shard_count > 1: this engine sweeps the shard_index-th of shard_count equal, contiguous */
     int32_t shard_count;     /*   ranges of the (view, cell) sequence instead of whole views (view_begin/view_stride ignored) */
-    int64_t max_patches;     /* patch pool capacity (0 = 4 * total cells) */
+    int64_t max_patches;     /* patch pool capacity (0 = 4 * total cells, at most a sixth of the free device memory per pool buffer) */
 } mvs_config;
 
 /* One view: PhotoSet::m_photos[i] (image/photoSet.hpp:62).  P is the row-major 3x4 level-0 projection

@@ -538,7 +538,14 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
     if (e->cnt.ensure(nc + 2) || e->start.ensure(nc + 2) || e->cursor.ensure(nc + 2) || e->vcnt.ensure(nc + 2) || e->vstart.ensure(nc + 2) ||
         e->vcursor.ensure(nc + 2) || e->dpgrid.ensure(nc + 2) || e->best.ensure(nc + 2) || e->cnt_alive.ensure(nc + 2) || e->vcnt_alive.ensure(nc + 2))
         return MVS_ERR_HIP;
-    const int64_t pool_cap = e->cfg.max_patches > 0 ? e->cfg.max_patches : 4 * nc;
+    // Pool capacity: mvs_config.max_patches, else 4 patches per cell (the 1080p runs settle near 1 per cell) -- but never
+    // more than a sixth of the free device memory for each of the two pool buffers: the index, staging and scans grow with it.
+    int64_t pool_cap = e->cfg.max_patches > 0 ? e->cfg.max_patches : 4 * nc;
+    if (e->cfg.max_patches <= 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
+            pool_cap = std::max<int64_t>(std::min<int64_t>(pool_cap, (int64_t)(free_b / 6 / sizeof(DPatch))), std::min<int64_t>(pool_cap, nc));
+    }
     if (e->pool.ensure(pool_cap) || e->pool_alt.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;
     HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)pool_cap, st));
     // jobs of one colour pass over every view (upper bound, used to size the staging bookkeeping)

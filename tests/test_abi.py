@@ -58,3 +58,18 @@ def test_create_rejects_bad_config_and_missing_gpu(lib):
         assert b"no HIP device" in lib.mvs_last_error()
         with pytest.raises(engine.EngineError):
             engine.Engine(3)
+
+
+def test_cap32_library_exports_the_same_abi():
+    """libmvskit_engine_cap32.so = the same sources built with -DMVS_LISTCAP=32 (view lists of up to 32 entries)."""
+    build.build_engine(cap32=True)
+    lib32 = engine.load_library(cap32=True)
+    for name in engine.EXPORTS:
+        assert hasattr(lib32, name), name
+    assert lib32.mvs_list_cap() == 32 and engine.load_library().mvs_list_cap() == 16
+
+
+def test_struct_sizes_of_the_binding():
+    # mvs_timing: 3 floats, int32, float, (pad), int64; mvs_filter_stats: 6 floats + 8 int64
+    assert C.sizeof(engine.Timing) == 32
+    assert C.sizeof(engine.FilterStats) == 24 + 8 * 8
