@@ -8,6 +8,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,6 +67,11 @@ Rccl& rccl() {
     static bool tried = false;
     if (tried) return r;
     tried = true;
+    // MVS_CCL_LIBRARY: another library with the same eight entry points (a site's own RCCL build; the shared-memory
+    // loopback of tests/loopback_ccl, which lets several ranks share the one GPU of a test box)
+    if (const char* over = getenv("MVS_CCL_LIBRARY")) {
+        if (*over) { r.h = dlopen(over, RTLD_NOW | RTLD_LOCAL); if (!r.h) return r; }
+    }
     const char* names[] = {"librccl.so", "librccl.so.1"};
     for (const char* n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     const char* paths[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};

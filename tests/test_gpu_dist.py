@@ -83,3 +83,72 @@ def test_gpu_ranks_equal_one_rank(tmp_path, world, ranged):
     for f in ("coord", "normal", "ncc", "dscale", "nimages", "images", "nvimages", "vimages"):
         for p in pools:
             np.testing.assert_array_equal(p[f], single[f], err_msg=f)
+
+
+LOOPBACK_DIR = os.path.join(ROOT, "tests", "loopback_ccl")
+LOOPBACK_LIB = os.path.join(LOOPBACK_DIR, "_build", "libloopback_ccl.so")
+
+
+def _worker_c_abi(rank, world, out_dir):
+    """One engine rank driven through the C ABI alone: mvs_engine_comm_init + mvs_engine_propagate (pass, mvs_engine_exchange,
+    commit of the union).  The collective library behind the engine is the shared-memory loopback (RCCL refuses ranks that
+    share a device); everything above it -- counts, offsets, in-place block broadcasts, kill ids, commit -- is the product code."""
+    import time
+
+    sys.path.insert(0, ROOT)
+    os.environ["MVS_CCL_LIBRARY"] = LOOPBACK_LIB
+    from mvskit_amd import engine
+
+    sc, seeds = _scene()
+    e = engine.Engine(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=5, device=0, shard_index=rank, shard_count=world)
+    e.set_scene(sc)
+    e.upload_patches(seeds)
+    uid_path = os.path.join(out_dir, "uid.bin")
+    if rank == 0:
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(e.comm_unique_id())
+        os.replace(uid_path + ".tmp", uid_path)
+    t0 = time.time()
+    while not os.path.exists(uid_path):
+        assert time.time() - t0 < 120, "rank 0 never published the communicator id"
+        time.sleep(0.05)
+    with open(uid_path, "rb") as f:
+        uid = f.read()
+    e.comm_init(uid, rank, world)
+    tot, moved = 0, 0
+    for it in range(ITERS):
+        tot += e.propagate(it)["patches"]
+        moved += e.timing()["exchange_bytes"]
+        e.update_threshold()
+    np.save(os.path.join(out_dir, f"pool_{rank}.npy"), e.patches().view(np.uint8))
+    np.save(os.path.join(out_dir, f"patches_{rank}.npy"), np.array([tot, moved]))
+    e.comm_release()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_c_abi_exchange_ranks_equal_one_rank(tmp_path, world):
+    """mvs_engine_exchange with world > 1 on one GPU: `world` processes, contiguous job ranges, the engine's own exchange
+    (what bench.py --gpus N and PmMvps::setRanks use on a node) over the loopback transport; every rank must end with
+    exactly the pool of the one-rank run."""
+    import subprocess
+
+    from mvskit_amd import engine
+
+    subprocess.check_call(["make", "-C", LOOPBACK_DIR, "-s"])
+    mp.spawn(_worker_c_abi, args=(world, str(tmp_path)), nprocs=world, join=True)
+    sc, seeds = _scene()
+    e = engine.Engine(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=5)
+    e.set_scene(sc)
+    e.upload_patches(seeds)
+    patches = 0
+    for it in range(ITERS):
+        patches += e.propagate(it)["patches"]
+        e.update_threshold()
+    single = e.patches()
+    pools = [np.load(tmp_path / f"pool_{r}.npy").view(engine.PATCH_DTYPE).reshape(-1) for r in range(world)]
+    stats = [np.load(tmp_path / f"patches_{r}.npy") for r in range(world)]
+    assert int(sum(s[0] for s in stats)) == patches and patches > 2000
+    assert all(int(s[1]) > 0 for s in stats)  # every rank received blocks from the others
+    for f in ("coord", "normal", "ncc", "dscale", "nimages", "images", "nvimages", "vimages"):
+        for p in pools:
+            np.testing.assert_array_equal(p[f], single[f], err_msg=f)
