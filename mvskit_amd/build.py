@@ -55,13 +55,14 @@ HOST_LIB_PATH = os.path.join(LIB_DIR, "libmvskit_host.so")
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """The host-side mirror of the reference classes (C++, g++), linked against the engine's C ABI."""
-    src = os.path.join(HOST_DIR, "pmmvps_host.cpp")
-    deps = [src, os.path.join(HOST_DIR, "pmmvps_host.hpp"), os.path.join(ROOT, "include", "mvskit_engine.h"), LIB_PATH]
+    srcs = [os.path.join(HOST_DIR, "pmmvps_host.cpp"), os.path.join(HOST_DIR, "jpeg_decode.cpp"), os.path.join(HOST_DIR, "ply_read.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, "pmmvps_host.hpp"), os.path.join(HOST_DIR, "jpeg_decode.hpp"), os.path.join(HOST_DIR, "ply_read.hpp"),
+                   os.path.join(ROOT, "include", "mvskit_engine.h"), LIB_PATH]
     if not force and os.path.exists(HOST_LIB_PATH) and os.environ.get("GRAFT_REPO_ROOT"):
         return HOST_LIB_PATH
     if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
         return HOST_LIB_PATH
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", HOST_LIB_PATH,
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), *srcs, "-o", HOST_LIB_PATH,
            "-L", LIB_DIR, "-lmvskit_engine", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))

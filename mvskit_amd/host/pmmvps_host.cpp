@@ -1,5 +1,7 @@
 // pmmvps_host.cpp -- see pmmvps_host.hpp.  Host code around the C ABI; nothing here computes the hot path.
 #include "pmmvps_host.hpp"
+#include "jpeg_decode.hpp"
+#include "ply_read.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -93,6 +95,7 @@ int Photo::initCamera(const string cname) {  // camera.cpp:27-63
     const float Rt[3][4] = {{c2 * c3, c3 * s2 * s1 - s3 * c1, c3 * s2 * c1 + s3 * s1, p[9]},
                             {s3 * c2, s3 * s2 * s1 + c3 * c1, s3 * s2 * c1 - c3 * s1, p[10]},
                             {-s2, c2 * s1, c2 * c1, p[11]}};
+    for (int y = 0; y < 3; ++y) for (int x = 0; x < 3; ++x) m_R[3 * y + x] = Rt[y][x];
     const float K[3][3] = {{p[0], p[2], p[3]}, {0.0f, p[1], p[4]}, {0.0f, 0.0f, 1.0f}};
     for (int y = 0; y < 3; ++y) for (int x = 0; x < 4; ++x) {
         float s = 0.0f;
@@ -119,6 +122,17 @@ int Photo::readPpm(const string iname) {
     m_image.resize((size_t)w * h * 3);
     is.read((char*)m_image.data(), (std::streamsize)m_image.size());
     return is ? 0 : -1;
+}
+int Photo::readJpeg(const string iname) {  // image.cpp:827-879
+    int w = 0, h = 0, ch = 0;
+    vector<unsigned char> px;
+    string err;
+    if (readJpegFile(iname, px, w, h, ch, &err) != 0) { cerr << "Couldn't read image " << iname << " (" << err << ")" << endl; return -1; }
+    m_width = w; m_height = h;
+    if (ch == 3) { m_image.swap(px); return 0; }
+    m_image.resize((size_t)w * h * 3);  // image.cpp:850-858
+    for (size_t i = 0; i < (size_t)w * h; ++i) m_image[3 * i] = m_image[3 * i + 1] = m_image[3 * i + 2] = px[i];
+    return 0;
 }
 int Photo::readPgmMask(const string mname) {
     ifstream is(mname.c_str(), std::ios::binary);
@@ -164,7 +178,10 @@ int PhotoSet::init(const vector<int>& images, const string prefix, const int nim
         snprintf(mname, sizeof mname, "%smask/%08d.pgm", prefix.c_str(), i);
         snprintf(cname, sizeof cname, "%stxt/%08d.txt", prefix.c_str(), i);
         if (m_photos[i].initCamera(cname) != 0) return -1;
-        if (m_photos[i].readPpm(iname) != 0) { cerr << "Unsupported image format found (only binary PPM): " << iname << endl; return -1; }
+        if (m_photos[i].readPpm(iname) != 0) {  // Image::completeName (image.cpp:51-74): <name>.ppm if it exists, else <name>.jpg
+            snprintf(iname, sizeof iname, "%simage/%04d%04d.jpg", prefix.c_str(), i, 0);
+            if (m_photos[i].readJpeg(iname) != 0) { cerr << "Unsupported image format found (binary PPM or JPEG): " << iname << endl; return -1; }
+        }
         if (m_photos[i].readPgmMask(mname) != 0) {  // Image::alloc tries .pgm, then .pbm (image.cpp:143-147)
             snprintf(mname, sizeof mname, "%smask/%08d.pbm", prefix.c_str(), i);
             (void)m_photos[i].readPbmMask(mname);
@@ -180,6 +197,24 @@ void PhotoSet::setPhoto(int index, int width, int height, const float P[12], con
     ph.m_image.assign(rgb, rgb + (size_t)width * height * 3);
     if (mask) ph.m_mask.assign(mask, mask + (size_t)width * height); else ph.m_mask.clear();
     m_nimages = (int)m_photos.size();
+}
+void PhotoSet::project(const int index, const Vector4f& coord, const int level, float icoord[3]) const {  // camera.cpp:310-326
+    const float* P = m_photos[index].m_projection;
+    const float s = 1.0f / (float)(1 << level);  // Camera::updateProjection (camera.cpp:91-100): rows 0 and 1 halved per level
+    float v[3];
+    for (int r = 0; r < 3; ++r) {
+        float a = 0.0f;
+        for (int k = 0; k < 4; ++k) a += (r < 2 ? P[4 * r + k] * s : P[4 * r + k]) * coord[k];
+        v[r] = a;
+    }
+    if (v[2] <= 0.0f) { icoord[0] = icoord[1] = -65535.0f; icoord[2] = -1.0f; return; }
+    icoord[0] = v[0] / v[2]; icoord[1] = v[1] / v[2]; icoord[2] = 1.0f;
+}
+int PhotoSet::getMask(const int index, const int ix, const int iy, const int level) const {  // image.cpp:765-781
+    const Photo& ph = m_photos[index];
+    if (level != 0 || ph.m_mask.empty()) return -1;
+    if (ix < 0 || ph.m_width <= ix || iy < 0 || ph.m_height <= iy) return -1;
+    return ph.m_mask[(size_t)iy * ph.m_width + ix];
 }
 int PhotoSet::image2index(const int image) const {  // photoSet.cpp:251-259
     auto pos = m_dict.find(image);
@@ -402,8 +437,149 @@ float Optim::computeNcc(const Patch& patch) {
     (void)probe(MVS_PROBE_NCC, p, &v);
     return v;
 }
-void DepthNormInit::createPatches() {  // depth_normal_init.cpp:29-33 (isTest)
-    if (m_pmmvps.m_patchManager.readPatches() != 0) cerr << "DepthNormInit::createPatches: no ply/00000000.patch under " << m_pmmvps.m_prefix << endl;
+// ---- DepthNormInit
+namespace {
+struct HostCamera {  // Camera::updateCamera (camera.cpp:65-89, getCameraCenter 295-308) + Optim::setAxesScales (optim.cpp:43-65)
+    float center[4], ipscale;
+};
+HostCamera host_camera(const Photo& ph) {
+    const float* P = ph.m_projection;
+    HostCamera c;
+    // centre = -M^-1 p4 (Eigen's 3x3 inverse is the cofactor formula)
+    const double m[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    const double inv[9] = {(m[4] * m[8] - m[5] * m[7]) / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
+                           (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
+                           (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
+    const double q[3] = {P[3], P[7], P[11]};
+    for (int r = 0; r < 3; ++r) c.center[r] = (float)-(inv[3 * r] * q[0] + inv[3 * r + 1] * q[1] + inv[3 * r + 2] * q[2]);
+    c.center[3] = 1.0f;
+    const float on = std::sqrt(P[8] * P[8] + P[9] * P[9] + P[10] * P[10]);
+    const float z[3] = {P[8] / on, P[9] / on, P[10] / on};
+    float x[3] = {P[0], P[1], P[2]};
+    float y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    const float yn = std::sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    for (int k = 0; k < 3; ++k) y[k] /= yn;
+    x[0] = y[1] * z[2] - y[2] * z[1]; x[1] = y[2] * z[0] - y[0] * z[2]; x[2] = y[0] * z[1] - y[1] * z[0];
+    c.ipscale = (P[0] * x[0] + P[1] * x[1] + P[2] * x[2]) + (P[4] * y[0] + P[5] * y[1] + P[6] * y[2]);
+    return c;
+}
+}  // namespace
+
+void DepthNormInit::sortImages(Patch& patch, const int isFixed) const {  // optim.cpp:221-258
+    const float threshold = 1.0f - std::cos(10.0f * (float)M_PI / 180.0f);
+    vector<int> indexes0, indexes1;
+    vector<float> units0, units1;
+    vector<std::array<float, 4> > rays0, rays1;
+    for (int image : patch.m_images) {  // computeUnits, optim.cpp:86-107
+        const HostCamera cam = host_camera(m_pmmvps.m_photoSet.m_photos[image]);
+        std::array<float, 4> ray;
+        for (int k = 0; k < 4; ++k) ray[k] = cam.center[k] - patch.m_coord[k];
+        const float fz = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2] + ray[3] * ray[3]);
+        for (int k = 0; k < 4; ++k) ray[k] /= fz;
+        const float dot = ray[0] * patch.m_normal[0] + ray[1] * patch.m_normal[1] + ray[2] * patch.m_normal[2] + ray[3] * patch.m_normal[3];
+        if (dot <= 0.0f) continue;
+        const float scale = cam.ipscale == 0.0f ? 1.0f : (float)(2.0 * fz * (0x0001 << m_pmmvps.m_level) / cam.ipscale);  // getUnit, optim.cpp:34-41
+        indexes0.push_back(image); units0.push_back(scale / dot); rays0.push_back(ray);
+    }
+    patch.m_images.clear();
+    if (indexes0.size() < 2) return;
+    if (isFixed) units0[0] = 0.0f;
+    while (!indexes0.empty()) {
+        const int index = (int)(std::min_element(units0.begin(), units0.end()) - units0.begin());
+        patch.m_images.push_back(indexes0[index]);
+        indexes1.clear(); units1.clear(); rays1.clear();
+        for (int i = 0; i < (int)rays0.size(); ++i) {
+            if (i == index) continue;
+            indexes1.push_back(indexes0[i]);
+            rays1.push_back(rays0[i]);
+            float d = 0.0f;
+            for (int k = 0; k < 4; ++k) d += rays0[index][k] * rays0[i][k];
+            const float ftmp = std::min(threshold, std::max(threshold / 2.0f, 1.0f - d));
+            units1.push_back(units0[i] * threshold / ftmp);
+        }
+        indexes1.swap(indexes0); units1.swap(units0); rays1.swap(rays0);
+    }
+}
+
+int DepthNormInit::readDepths(vector<std::array<float, 3> >& coords) {  // depth_normal_init.cpp:94-112
+    char dname[1024];
+    snprintf(dname, sizeof dname, "%sply/%08d.ply", m_prefix.c_str(), 0);
+    vector<double> points;
+    string err;
+    if (readPlyVertices(dname, points, nullptr, &err) != 0) { cerr << "DepthNormInit::readDepths: " << err << endl; return -1; }
+    coords.resize(points.size() / 3);
+    for (size_t i = 0; i < coords.size(); ++i) coords[i] = {(float)points[3 * i], (float)points[3 * i + 1], (float)points[3 * i + 2]};
+    return 0;
+}
+int DepthNormInit::readNormals(vector<vector<std::array<float, 3> > >& normals) {  // depth_normal_init.cpp:114-144
+    for (int i = 0; i < m_nplys - 1; ++i) {
+        char nname[1024];
+        snprintf(nname, sizeof nname, "%sply/%08d.ply", m_prefix.c_str(), i + 1);
+        vector<double> points, norms;
+        string err;
+        if (readPlyVertices(nname, points, &norms, &err) != 0) { cerr << "DepthNormInit::readNormals: " << err << endl; return -1; }
+        if (norms.empty()) { cerr << "DepthNormInit::readNormals: no nx ny nz in " << nname << endl; return -1; }
+        const Photo& ph = m_pmmvps.m_photoSet.m_photos[i];
+        if (ph.m_txtType != 2) { cerr << "Not supported: " << ph.m_txtType << endl; return -1; }  // Camera::setR, camera.cpp:180-183
+        const int width = ph.m_width, height = ph.m_height;
+        normals[i].assign((size_t)width * height, std::array<float, 3>{0.0f, 0.0f, 0.0f});
+        for (size_t n = 0; n < points.size() / 3; ++n) {
+            const int x = (int)points[3 * n], y = (int)points[3 * n + 1];
+            if (x < 0 || width <= x || y < 0 || height <= y) continue;  // the reference writes out of bounds here
+            const float v[3] = {(float)norms[3 * n], (float)norms[3 * n + 1], (float)norms[3 * n + 2]};
+            std::array<float, 3> r;
+            for (int k = 0; k < 3; ++k) r[k] = ph.m_R[3 * k] * v[0] + ph.m_R[3 * k + 1] * v[1] + ph.m_R[3 * k + 2] * v[2];
+            normals[i][(size_t)y * width + x] = r;
+        }
+    }
+    return 0;
+}
+int DepthNormInit::buildPatches(vector<Ppatch>& ppatches) {  // depth_normal_init.cpp:34-91
+    if (m_nplys <= 0) init(m_pmmvps.m_prefix, m_pmmvps.m_nimages + 1);  // pmmvps.cpp:45
+    vector<std::array<float, 3> > coords;
+    if (readDepths(coords) != 0) return -1;
+    vector<vector<std::array<float, 3> > > normals((size_t)std::max(0, m_nplys - 1));
+    if (readNormals(normals) != 0) return -1;
+    const PhotoSet& ps = m_pmmvps.m_photoSet;
+    for (size_t i = 0; i < coords.size(); ++i) {
+        Ppatch ppatch(new Patch());
+        ppatch->m_coord = {coords[i][0], coords[i][1], coords[i][2], 1.0f};
+        vector<int> images;
+        float n3[3] = {0.0f, 0.0f, 0.0f};
+        for (int image = 0; image < m_pmmvps.m_nimages && image < (int)normals.size(); ++image) {
+            float icoord[3];
+            ps.project(image, ppatch->m_coord, 0, icoord);
+            const int x = (int)floorf(icoord[0] + 0.5f), y = (int)floorf(icoord[1] + 0.5f);
+            if (ps.getMask(image, x, y, 0) <= 0) continue;  // also skips every view without a mask (getMask = -1), as the reference does
+            const std::array<float, 3>& nv = normals[image][(size_t)y * ps.getWidth(image, 0) + x];
+            for (int k = 0; k < 3; ++k) n3[k] += nv[k];
+            images.push_back(image);
+        }
+        float norm = std::sqrt(n3[0] * n3[0] + n3[1] * n3[1] + n3[2] * n3[2]);
+        if (images.size() < 2 || norm == 0.0f) continue;
+        ppatch->m_images = images;
+        for (int k = 0; k < 3; ++k) n3[k] /= (float)images.size();
+        norm = std::sqrt(n3[0] * n3[0] + n3[1] * n3[1] + n3[2] * n3[2]);
+        for (int k = 0; k < 3; ++k) n3[k] /= norm;
+        ppatch->m_normal = {n3[0], n3[1], n3[2], -(coords[i][0] * n3[0] + coords[i][1] * n3[1] + coords[i][2] * n3[2])};
+        sortImages(*ppatch, 0);
+        // the reference adds a patch even when sortImages left fewer than two views (m_images empty: it then sits in no
+        // grid cell); the engine's pool holds no such patch
+        if (ppatch->m_images.empty()) continue;
+        ppatch->m_nimages = (int)ppatch->m_images.size();
+        ppatches.push_back(ppatch);  // setGrids / addPatch: the engine computes cells and depth maps on upload
+    }
+    return 0;
+}
+void DepthNormInit::createPatches() {  // depth_normal_init.cpp:29-91
+    if (m_isTest) {
+        if (m_pmmvps.m_patchManager.readPatches() != 0) cerr << "DepthNormInit::createPatches: no ply/00000000.patch under " << m_pmmvps.m_prefix << endl;
+        return;
+    }
+    vector<Ppatch> pp;
+    if (buildPatches(pp) != 0) { m_pmmvps.m_status = MVS_ERR_ARG; return; }
+    m_pmmvps.m_patchManager.addPatches(pp);
 }
 
 // ------------------------------------------------------------------ Filter
@@ -493,7 +669,7 @@ void PmMvps::init(const Option& option, const PhotoSet& photos) {  // pmmvps.cpp
     m_quadThreshold = option.m_quadThreshold;
     if (int r = createEngine(option.m_maxAngleThreshold, option.m_quadThreshold)) { m_status = r; return; }
     m_patchManager.init();
-    m_dnInit.init();
+    m_dnInit.init(m_prefix, m_nimages + 1);  // pmmvps.cpp:45
     m_propagate.init();
     m_optim.init();
     m_filter.init();
@@ -579,6 +755,9 @@ extern "C" int mvshost_run(int nviews, int width, int height, const float* P /*[
 // The reference's own driver sequence on a dataset directory (test/test.cpp:155-161): Option::init(prefix, "option"),
 // PmMvps::init(option) (cameras txt/%08d.txt, images image/%04d%04d.ppm, masks mask/%08d.pgm), PmMvps::run (seeds from
 // ply/00000000.patch; ply/refined_patches_<iter>.ply written after every iteration).  Returns the final patches.
+// the next mvshost_run_dataset takes its seeds from ply/00000000.ply + the per-view normal maps (DepthNormInit::m_isTest = 0)
+static bool g_seed_plys = false;
+extern "C" void mvshost_set_seed_plys(int on) { g_seed_plys = on != 0; }
 extern "C" int mvshost_run_dataset(const char* prefix, int iters, unsigned seed, long long cap, mvs_patch* out, long long* nout) {
     using namespace mvshost;
     Option option;
@@ -587,6 +766,7 @@ extern "C" int mvshost_run_dataset(const char* prefix, int iters, unsigned seed,
     PmMvps pmmvps;
     pmmvps.m_seed = seed; pmmvps.ITER = iters; pmmvps.m_writeFiles = true;
     pmmvps.init(option);
+    pmmvps.m_dnInit.m_isTest = g_seed_plys ? 0 : 1;
     pmmvps.run();
     if (pmmvps.m_status) return pmmvps.m_status;
     pmmvps.m_patchManager.collectPatches();
@@ -660,4 +840,30 @@ extern "C" int mvshost_camera_probe(const char* cname, float* P12) {
     const int r = ph.initCamera(cname);
     memcpy(P12, ph.m_projection, sizeof ph.m_projection);
     return r;
+}
+// Photo::readJpeg on a file: interleaved RGB into out (capacity bytes); returns 0, -1 (unreadable) or -2 (capacity)
+extern "C" int mvshost_jpeg_probe(const char* iname, int* width, int* height, unsigned char* out, long long capacity) {
+    mvshost::Photo ph;
+    if (ph.readJpeg(iname) != 0) return -1;
+    *width = ph.m_width; *height = ph.m_height;
+    if (out) { if ((long long)ph.m_image.size() > capacity) return -2; memcpy(out, ph.m_image.data(), ph.m_image.size()); }
+    return 0;
+}
+// DepthNormInit's PLY branch (m_isTest = 0) on a dataset directory, host part only (no engine): Option::init, PhotoSet::init,
+// DepthNormInit::buildPatches.  Returns the number of seed patches (the first `cap` in out) or a negative status.
+extern "C" long long mvshost_seeds_from_plys(const char* prefix, long long cap, mvs_patch* out) {
+    using namespace mvshost;
+    Option option;
+    option.init(prefix, "option");
+    if (option.m_status != 0) return -1;
+    PmMvps pmmvps;
+    pmmvps.m_images = option.m_images; pmmvps.m_nimages = option.m_nimages; pmmvps.m_prefix = option.m_prefix;
+    pmmvps.m_level = option.m_level; pmmvps.m_csize = option.m_csize;
+    if (pmmvps.m_photoSet.init(option.m_images, option.m_prefix, option.m_nimages, option.m_nillums, option.m_level + 3, option.m_wsize, 1) != 0) return -2;
+    pmmvps.m_dnInit.init(option.m_prefix, option.m_nimages + 1);
+    pmmvps.m_dnInit.m_isTest = 0;
+    vector<Ppatch> pp;
+    if (pmmvps.m_dnInit.buildPatches(pp) != 0) return -3;
+    for (long long i = 0; i < std::min<long long>(cap, (long long)pp.size()); ++i) out[i] = to_record(*pp[i]);
+    return (long long)pp.size();
 }

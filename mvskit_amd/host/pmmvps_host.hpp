@@ -53,10 +53,13 @@ struct Photo {
     vector<unsigned char> m_image;      // Image::m_images[0], interleaved RGB
     vector<unsigned char> m_mask;       // Image::m_masks[0] or empty
     int m_txtType = 0;
+    float m_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // Camera::setR (camera.cpp:179-197): the rotation of a CONTOUR2 camera, row-major
     // Camera::init for CONTOUR / CONTOUR2 text files (camera.cpp:27-63,102-141,241-261)
     int initCamera(const string cname);
     // binary PPM (P6) reader; PhotoSet::init accepts `image/%04d%04d.ppm` (photoSet.cpp:33-36)
     int readPpm(const string iname);
+    // Image::readJpeg (image.cpp:827-879): grey files become R = G = B; decoder in jpeg_decode.cpp
+    int readJpeg(const string iname);
     int readPgmMask(const string mname);  // P5, thresholded at 127 (image.cpp:170-177)
     int readPbmMask(const string mname);  // P4, Image::readPBMImage (image.cpp:881-946)
 };
@@ -69,6 +72,8 @@ public:
     void setPhoto(int index, int width, int height, const float P[12], const unsigned char* rgb, const unsigned char* mask);
     int getWidth(const int index, const int level) const { return m_photos[index].m_width >> level; }
     int getHeight(const int index, const int level) const { return m_photos[index].m_height >> level; }
+    void project(const int index, const Vector4f& coord, const int level, float icoord[3]) const;  // photoSet.cpp:243 -> camera.cpp:310-326
+    int getMask(const int index, const int ix, const int iy, const int level) const;               // photoSet.cpp:215 -> image.cpp:765-781 (level 0 only here)
     int image2index(const int image) const;
     vector<Photo> m_photos;
     vector<int> m_images;
@@ -149,16 +154,27 @@ protected:
     PmMvps& m_pmmvps;
 };
 
-// pmmvps/depth_normal_init.hpp:20-44: the reference hard-wires isTest = 1 (depth_normal_init.cpp:30), i.e. the seeds are
-// PatchManager::readPatches() of ply/00000000.patch; the disabled depth-PLY + normal-PLY branch (:34-144) is not built.
+// pmmvps/depth_normal_init.hpp:20-44.  The reference hard-wires isTest = 1 (depth_normal_init.cpp:30): the seeds are
+// PatchManager::readPatches() of ply/00000000.patch.  Its other branch (:34-91, readDepths :94-112, readNormals :114-144) --
+// seeds from a point cloud ply/00000000.ply and one normal map per view ply/%08d.ply (vertex = pixel x y, normal in camera
+// axes) -- runs when m_isTest is set to 0.
 class DepthNormInit {
 public:
     explicit DepthNormInit(PmMvps& pmmvps) : m_pmmvps(pmmvps) {}
     void init() {}
+    void init(const string prefix, const int nfiles) { m_prefix = prefix; m_nplys = nfiles; }  // depth_normal_init.cpp:24-27
     void createPatches();
+    // the host part of the PLY branch: the patches createPatches() then hands to PatchManager (no engine involved)
+    int buildPatches(vector<Ppatch>& ppatches);
+    int m_isTest = 1;
 
 protected:
+    int readDepths(vector<std::array<float, 3> >& coords);
+    int readNormals(vector<vector<std::array<float, 3> > >& normals);
+    void sortImages(Patch& patch, const int isFixed) const;  // Optim::sortImages, optim.cpp:221-258 (+ computeUnits 86-107, getUnit 34-41)
     PmMvps& m_pmmvps;
+    string m_prefix;
+    int m_nplys = 0;
 };
 
 // pmmvps/filter.hpp:24-63

@@ -282,3 +282,80 @@ def test_dataset_on_disk_equals_in_memory_run(host, small_plane_scene, tmp_path)
     txt = (root / "ply" / "final.patch").read_text().split()
     assert txt[0] == "PATCHES" and int(txt[1]) == nf.value
     np.testing.assert_allclose([float(x) for x in txt[3:6]], a["coord"][0][:3], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_jpeg_contour2_ply_seed_dataset(host, small_plane_scene, tmp_path):
+    """The ingestion the reference's own data sets use, end to end: CONTOUR2 cameras (camera.cpp:117-134), JPEG images
+    (image.cpp:827-879; written here by PIL, read by the mirror's decoder), PGM masks, seeds from a point-cloud PLY plus one
+    normal-map PLY per view (depth_normal_init.cpp:34-144).  PmMvps::run on the directory must give exactly the patches of
+    the in-memory run on PIL's pixels, the probed projections and the seeds DepthNormInit::buildPatches reports."""
+    pytest.importorskip("PIL")
+    import scipy.linalg
+    from PIL import Image
+
+    host.mvshost_set_seed_plys.argtypes = [C.c_int]
+    host.mvshost_set_seed_plys.restype = None
+    host.mvshost_seeds_from_plys.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p]
+    host.mvshost_seeds_from_plys.restype = C.c_longlong
+    sc = small_plane_scene
+    root = tmp_path / "data"
+    for d in ("txt", "image", "mask", "ply"):
+        (root / d).mkdir(parents=True)
+    (root / "option").write_text(f"level 0\ncsize 2\nthreshold 0.7\nwsize 7\nminImageNum 2\nimages -1 0 {sc.nviews}\n")
+    P_host = np.zeros((sc.nviews, 3, 4), np.float32)
+    decoded = np.zeros_like(sc.images)
+    n_world = np.array([0.0, 0.0, 1.0])
+    for v in range(sc.nviews):
+        K, R = scipy.linalg.rq(sc.P[v][:, :3].astype(np.float64))
+        S = np.diag(np.sign(np.diag(K)))
+        K, R = K @ S, S @ R
+        t = np.linalg.solve(K, sc.P[v][:, 3].astype(np.float64))
+        K = K / K[2, 2]
+        b = -math.asin(R[2, 0])
+        a, g = math.atan2(R[2, 1], R[2, 2]), math.atan2(R[1, 0], R[0, 0])
+        vals = [K[0, 0], K[1, 1], K[0, 1], K[0, 2], K[1, 2], 0.0, math.degrees(a), math.degrees(b), math.degrees(g), t[0], t[1], t[2]]
+        (root / "txt" / f"{v:08d}.txt").write_text("CONTOUR2\n" + " ".join(repr(float(x)) for x in vals) + "\n")
+        assert host.mvshost_camera_probe(str(root / "txt" / f"{v:08d}.txt").encode(), P_host[v].ctypes.data) == 0
+        np.testing.assert_allclose(P_host[v] / P_host[v][2, 3], sc.P[v] / sc.P[v][2, 3], rtol=0, atol=2e-3)
+        Image.fromarray(sc.images[v]).save(root / "image" / f"{v:04d}0000.jpg", quality=95, subsampling=1)
+        decoded[v] = np.asarray(Image.open(root / "image" / f"{v:04d}0000.jpg"))
+        with open(root / "mask" / f"{v:08d}.pgm", "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (sc.W, sc.H) + bytes([255]) * (sc.W * sc.H))
+        ys, xs = np.mgrid[0:sc.H, 0:sc.W]
+        n_cam = R.T @ (n_world if (R @ n_world)[2] < 0 else -n_world)  # towards the camera; the mirror rotates it back with R
+        with open(root / "ply" / f"{v + 1:08d}.ply", "wb") as f:
+            f.write(f"ply\nformat binary_little_endian 1.0\nelement vertex {sc.W * sc.H}\nproperty float x\nproperty float y\nproperty float z\n"
+                    "property float nx\nproperty float ny\nproperty float nz\nend_header\n".encode())
+            rec = np.zeros((sc.H, sc.W, 6), "<f4")
+            rec[..., 0], rec[..., 1] = xs, ys
+            rec[..., 3:] = n_cam
+            f.write(rec.tobytes())
+    seeds0 = synth.make_seeds(sc, stride=4, seed=21)
+    with open(root / "ply" / "00000000.ply", "w") as f:
+        f.write(f"ply\nformat ascii 1.0\nelement vertex {seeds0.shape[0]}\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+        for r in seeds0:
+            f.write(" ".join(repr(float(x)) for x in r["coord"][:3]) + "\n")
+    prefix = (str(root) + "/").encode()
+    seeds = np.zeros(seeds0.shape[0], dtype=engine.PATCH_DTYPE)
+    ns = host.mvshost_seeds_from_plys(prefix, seeds.shape[0], seeds.ctypes.data)
+    assert 0.8 * seeds0.shape[0] <= ns <= seeds0.shape[0]
+    seeds = np.ascontiguousarray(seeds[:ns])
+    assert np.all(seeds["nimages"] >= 2)
+    iters, cap = 2, 200000
+    out_f = np.zeros(cap, dtype=engine.PATCH_DTYPE)
+    nf = C.c_longlong()
+    host.mvshost_set_seed_plys(1)
+    try:
+        assert host.mvshost_run_dataset(prefix, iters, 9, cap, out_f.ctypes.data, C.byref(nf)) == 0
+    finally:
+        host.mvshost_set_seed_plys(0)
+    out_m = np.zeros(cap, dtype=engine.PATCH_DTYPE)
+    nm, ptot = C.c_longlong(), C.c_longlong()
+    img = np.ascontiguousarray(decoded)
+    assert host.mvshost_run(sc.nviews, sc.W, sc.H, P_host.ctypes.data, img.ctypes.data, 0, 2, 7, 2, C.c_float(0.7), 9, iters, seeds.shape[0], seeds.ctypes.data,
+                            cap, out_m.ctypes.data, C.byref(nm), C.byref(ptot)) == 0
+    assert nf.value == nm.value and nf.value > 2 * ns
+    a, b = out_f[: nf.value], out_m[: nm.value]
+    for f in ("coord", "normal", "ncc", "nimages", "images"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
