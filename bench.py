@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--seed-stride", type=int, default=2, help="one seed patch per stride x stride cells per view")
-    ap.add_argument("--refine-steps", type=int, default=8)
+    ap.add_argument("--refine-steps", type=int, default=6)  # four proposals per step: 1 + 4 * 6 = 25 cost evaluations per candidate
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--filter", action="store_true", help="BASELINE config 5: run Filter::run (filter.cpp:25-49) after every iteration, inside the timed region")
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal: run the N>1 code path (RCCL exchange) with a world of 1")
@@ -302,7 +302,7 @@ def main():
                                    f"m_depth 1/2/3, Optim::check from m_depth 2) run {reps} time(s)" + (f" + its first {extra} iteration(s)" if extra else "")
                                    + f" = {args.steps} timed steps after {args.warmup} warm-up step(s); pool and thresholds reset between repetitions outside the timed region",
                        "views": args.views, "width": args.width, "height": args.height, "csize": 2, "wsize": 7, "iterations_per_repetition": SCHEDULE_ITERS,
-                       "repetitions": reps, "extra_iterations": extra, "refine_evals": 1 + 3 * args.refine_steps, "check_depth2": True, "filter_run": bool(args.filter),
+                       "repetitions": reps, "extra_iterations": extra, "refine_evals": 1 + 4 * args.refine_steps, "check_depth2": True, "filter_run": bool(args.filter),
                        "parallelism": "single GPU" if world == 1 else f"the (view, cell) sequence sharded in {world} contiguous ranges over {world} ranks; per colour pass: {exchange}"},
             "patches": patches,
             "patches_by_iteration": patches_by_iter if world == 1 else None,

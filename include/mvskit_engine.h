@@ -67,7 +67,7 @@ typedef struct mvs_config {
     float quadThreshold;     /* Option::m_quadThreshold */
     int32_t depth;           /* PmMvps::m_depth when Propagate::run is entered */
     uint32_t seed;           /* counter-based RNG seed */
-    int32_t refine_steps;    /* halving steps of the refiner; 1 + 3*steps cost evaluations */
+    int32_t refine_steps;    /* halving steps of the refiner, four proposals each; 1 + 4*steps cost evaluations (default 6: 25) */
     float refine_rd0;        /* initial depth range in units of Patch::m_dscale */
     float refine_ra0;        /* initial angle range in units of pi/48 (optim.cpp:487) */
     int32_t enable_check;    /* Optim::check when depth >= 2 (optim.cpp:292) */

@@ -7,7 +7,7 @@
 //     1,2,4,8,16,32;
 //   * view lanes: lane j holds element j of a per-view array (Patch::m_images[j], its ray, unit, INCC ...),
 //     read back with v_readlane when a loop needs element j uniformly;
-//   * frame lanes: lane 16*g + i holds the sampling frame of view i for proposal g (g < 3): the three
+//   * frame lanes: lane 16*g + i holds the sampling frame of view i for proposal g (g < 4): the four
 //     proposals of one refinement step share one pass of decode / getPAxes / projection arithmetic.
 // Per-view scalars that need a square root or a division (msd, 1/msd, robust INCC) are gathered into view
 // lanes first, so one vector instruction sequence serves all views of an evaluation.
@@ -410,8 +410,8 @@ DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int
 #ifndef MVS_FRAME_LDS
 #define MVS_FRAME_LDS 1
 #endif
-#define MVS_PIVOT_LDS4 144                         // float4 index of the per-view pivot colours (refinePatch, class lanes)
-#define MVS_FRAME_LDS_BYTES (48 * 48 + 16 * 16)    // frame lanes 0..47, 12 dwords each, + 16 pivots; the start of the kernel's dynamic LDS
+#define MVS_PIVOT_LDS4 192                         // float4 index of the per-view pivot colours (refinePatch, class lanes)
+#define MVS_FRAME_LDS_BYTES (64 * 48 + 16 * 16)    // frame lanes 0..63, 12 dwords each, + 16 pivots; the start of the kernel's dynamic LDS
 #define MVS_FRAME1_LDS_BYTES (48 * (MVS_LISTCAP > 16 ? MVS_LISTCAP : 16))  // what a single-proposal evaluation publishes there
 extern __shared__ float4 mvs_dyn_lds4[];
 DEV void frames_publish(const WaveCtx& wc, const Frame& f, int nlanes) {
@@ -587,43 +587,39 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
     incc_l = 1.0f - (dot_l * (inv0_l * inv_l)) * prm.inv_3sz;
 }
 
-// ------------------------------------------------------------------ class-lane evaluation (the three proposals of a refinement step)
-// Optim::getTex sampling + normalize + dot for proposals g = 0..2 against the views k < n, with a lane per (proposal,
+// ------------------------------------------------------------------ class-lane evaluation (the four proposals of a refinement step)
+// Optim::getTex sampling + normalize + dot for proposals g = 0..3 against the views k < n, with a lane per (proposal,
 // sample class) instead of a lane per sample: lane 16 g + c walks its samples c, c + 16, c + 32 of EVERY view and keeps
 // running sums -- colour, colour^2 and colour x reference colour (the reference view's colours of its own samples stay in
 // registers) -- so no sum crosses lanes per sample.  Per view the five sums are finished by the four DPP steps of a
-// 16-lane row, once for all three proposals, and dropped into view lane 16 g + k; the per-view scalars (1/msd, INCC) then
-// come out of one vector sequence as in eval_core.  Per (proposal, view, sample) that is ~57 vector instructions instead
-// of 104, and a wave instruction covers 48-51 samples.
+// 16-lane row, once for all four proposals, and dropped into view lane 16 g + k; the per-view scalars (1/msd, INCC) then
+// come out of one vector sequence as in eval_core.  A wave instruction of the view loop covers 64 samples.
+// The few samples beyond the last full 16 ("extras": sample 48 of a 7x7 window) are taken afterwards by the FRAME lanes:
+// lane 16 g + k samples them in its own frame (proposal g, view k) and adds them to the sums it has just received.
 // Arithmetic (mirrored by the oracle, tex_stats_class16): colours are taken relative to a per-view pivot p (the view's
 // mean colour in refinePatch's first evaluation), c' = blend - p;  S1 = sum c', S2 = sum |c'|^2, S01 = sum c' . c0';
 // mean m = S1 / n;  ssd = max(S2 - S1 . m, 0);  dot = S01 - S1 . m0;  INCC = 1 - dot (inv0 inv) / 3n.  The sums run
-// j-ascending inside a lane, the extras lane is added to lane 16 g + e, then the row tree pairs lanes 1, 2, 4, 8 apart.
+// j-ascending inside a lane, the row tree pairs lanes 1, 2, 4, 8 apart, the extras are added last, in sample order.
 struct ClsPend { Texel2 q0, q1; float dx1, dy1; };
-// Per-lane constants of the class-lane layout: lane 16 g + c of rows g < 3 owns samples c, c + 16, c + 32 of proposal g;
-// the few samples beyond the last full 16 ("extras", sample 48 of a 7x7 window) sit in row 3, lane 48 + 3 e + g.
+// Per-lane constants of the class-lane layout: lane 16 g + c owns samples c, c + 16, c + 32 of proposal g.
 struct ClsConst {
     unsigned cs[3];  // per iteration j: fx | fy << 8 | valid << 16
     int fb;          // first frame lane of this lane's proposal (16 g)
-    int pull;        // ds_bpermute address (4 * lane) of the extras lane whose sums this lane adds to its own
-    float pullm;     // 1 on lanes that pull, else 0
+    int xbase, nx;   // the extras: samples xbase .. xbase + nx - 1 (wave-uniform)
 };
 DEV ClsConst make_cls(const DParams& prm, const WaveCtx& wc) {
     ClsConst cc;
     const int wsz = prm.wsz, nj = wsz >> 4, rem = wsz & 15;
     const int rx = rem <= 5 ? rem : 0, njx = nj + (rem > 5 ? 1 : 0);
-    const int row = wc.lane >> 4, c = wc.lane & 15, t = wc.lane - 48;
-    cc.fb = 16 * (row < 3 ? row : t % 3);
-    const int e = t / 3;
+    const int row = wc.lane >> 4, c = wc.lane & 15;
+    cc.fb = 16 * row;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int s = row < 3 ? c + 16 * j : 16 * nj + e;
-        const bool valid = row < 3 ? (j < njx && s < (rem > 5 ? wsz : 16 * nj)) : (j == 0 && e < rx);
+        const int s = c + 16 * j;
+        const bool valid = j < njx && s < (rem > 5 ? wsz : 16 * nj);
         cc.cs[j] = valid ? (unsigned)(s % prm.wsize) | ((unsigned)(s / prm.wsize) << 8) | (1u << 16) : 0u;
     }
-    const bool pulls = row < 3 && c < rx;
-    cc.pull = 4 * (pulls ? 48 + 3 * c + row : wc.lane);
-    cc.pullm = pulls ? 1.0f : 0.0f;
+    cc.xbase = 16 * nj; cc.nx = rx;
     return cc;
 }
 DEV float cvt_ub0(unsigned x) { return (float)(x & 255u); }
@@ -681,13 +677,13 @@ DEV float bperm_f(int addr, float x) { return __int_as_float(__builtin_amdgcn_ds
 // Leaves in frame lane 16 g + k (k >= 1) the INCC of view k against the reference view of proposal g.
 // Straight-line per view (always three sample slots per lane; a slot without a sample contributes exact zeros), the
 // reference view peeled off, and the loads of view k + 1 issued as the slots of view k are consumed.
-DEV void eval_steps3(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const Frame& f, int n, unsigned (&okm)[3], float& incc_l) {
-    frames_publish(wc, f, 48);
+DEV void eval_steps4(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const Frame& f, int n, unsigned (&okm)[4], float& incc_l) {
+    frames_publish(wc, f, 64);
     const unsigned long long okb = ballot(f.ok != 0);
 #pragma unroll
-    for (int g = 0; g < 3; ++g) okm[g] = (unsigned)((okb >> (16 * g)) & 0xffffull);
+    for (int g = 0; g < 4; ++g) okm[g] = (unsigned)((okb >> (16 * g)) & 0xffffull);
 #pragma unroll
-    for (int g = 0; g < 3; ++g) wc.view_evals += (okm[g] & 1u) ? (unsigned)__popc(okm[g]) : 0u;
+    for (int g = 0; g < 4; ++g) wc.view_evals += (okm[g] & 1u) ? (unsigned)__popc(okm[g]) : 0u;
     const int fb = cc.fb;
     const int lc = wc.lane & 15;
     float c0[3][3];
@@ -712,10 +708,6 @@ DEV void eval_steps3(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const 
             s1r += r; s1g += g; s1b += b;
             s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
         }
-        s1r = fma_(bperm_f(cc.pull, s1r), cc.pullm, s1r);
-        s1g = fma_(bperm_f(cc.pull, s1g), cc.pullm, s1g);
-        s1b = fma_(bperm_f(cc.pull, s1b), cc.pullm, s1b);
-        s2 = fma_(bperm_f(cc.pull, s2), cc.pullm, s2);
         MVS_ROW_STEP4(0xB1) MVS_ROW_STEP4(0x4E) MVS_ROW_STEP4(0x141) MVS_ROW_STEP4(0x140)
         P1r = s1r; P1g = s1g; P1b = s1b; P2 = s2;  // lanes lc != 0 are overwritten below or unused
     }
@@ -733,20 +725,33 @@ DEV void eval_steps3(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const 
             s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
             s01 = fma_(r, c0[j][0], s01); s01 = fma_(g, c0[j][1], s01); s01 = fma_(b, c0[j][2], s01);
         }
-        // the extras lane's sums join lane 16 g + e, then the row tree (lanes 1, 2, 4, 8 apart)
-        s1r = fma_(bperm_f(cc.pull, s1r), cc.pullm, s1r);
-        s1g = fma_(bperm_f(cc.pull, s1g), cc.pullm, s1g);
-        s1b = fma_(bperm_f(cc.pull, s1b), cc.pullm, s1b);
-        s2 = fma_(bperm_f(cc.pull, s2), cc.pullm, s2);
-        s01 = fma_(bperm_f(cc.pull, s01), cc.pullm, s01);
-        MVS_ROW_STEP5(0xB1) MVS_ROW_STEP5(0x4E) MVS_ROW_STEP5(0x141) MVS_ROW_STEP5(0x140)
+        MVS_ROW_STEP5(0xB1) MVS_ROW_STEP5(0x4E) MVS_ROW_STEP5(0x141) MVS_ROW_STEP5(0x140)  // the row tree (lanes 1, 2, 4, 8 apart)
         if (lc == k) { P1r = s1r; P1g = s1g; P1b = s1b; P2 = s2; P01 = s01; }
+    }
+    const int a0 = (wc.lane & 48) << 2;  // ds_bpermute address of lane 16 g: the reference view of this lane's proposal
+    // the extras: frame lane 16 g + k samples them in its own frame (a frame that does not sample holds a harmless address
+    // and its sums are never looked at) and adds them to the sums of (proposal g, view k) it holds
+    if (cc.nx > 0) {
+        const float4 pv = mvs_dyn_lds4[MVS_PIVOT_LDS4 + lc];
+        ClsFrame fr;
+        fr.tlx = f.tlx; fr.tly = f.tly; fr.dxx = f.dxx; fr.dxy = f.dxy; fr.dyx = f.dyx; fr.dyy = f.dyy; fr.w = f.w;
+        fr.base = ((unsigned long long)f.img_hi << 32) | (unsigned long long)f.img_lo;
+        for (int e = 0; e < cc.nx; ++e) {
+            const int q = cc.xbase + e;
+            const unsigned cs = (unsigned)(q % prm.wsize) | ((unsigned)(q / prm.wsize) << 8) | (1u << 16);
+            const ClsPend pe = cls_issue(fr, cs);
+            float r, g, b;
+            cls_colour(pe, cs, pv.x, pv.y, pv.z, r, g, b);
+            const float r0 = bperm_f(a0, r), g0 = bperm_f(a0, g), b0 = bperm_f(a0, b);
+            P1r += r; P1g += g; P1b += b;
+            P2 = fma_(r, r, P2); P2 = fma_(g, g, P2); P2 = fma_(b, b, P2);
+            P01 = fma_(r, r0, P01); P01 = fma_(g, g0, P01); P01 = fma_(b, b0, P01);
+        }
     }
     // view lane 16 g + k: mean, ssd, centred product of view k; the reference view's mean and 1/msd come from lane 16 g
     const float m_r = P1r * prm.inv_sz, m_g = P1g * prm.inv_sz, m_b = P1b * prm.inv_sz;
     const float ssd = fmaxf(P2 - fma_(P1b, m_b, fma_(P1g, m_g, P1r * m_r)), 0.0f);
     const float inv_l = inv_msd(prm, ssd);
-    const int a0 = (wc.lane & 48) << 2;
     const float m0r = bperm_f(a0, m_r), m0g = bperm_f(a0, m_g), m0b = bperm_f(a0, m_b), inv0 = bperm_f(a0, inv_l);
     const float dot = P01 - fma_(P1b, m0b, fma_(P1g, m0g, P1r * m0r));
     incc_l = 1.0f - (dot * (inv0 * inv_l)) * prm.inv_3sz;
@@ -1041,7 +1046,7 @@ DEV void decode(const DParams& prm, const RefineCtx& rc, float x0, float x1, flo
               fma_(vw->zaxis[1], fz, fma_(vw->yaxis[1], fy, vw->xaxis[1] * fx)),
               fma_(vw->zaxis[2], fz, fma_(vw->yaxis[2], fy, vw->xaxis[2] * fx)), 0.0f};
 }
-// Optim::cost_func (optim.cpp:401-468) for up to three proposals at once: lane 16*g + i decodes proposal g
+// Optim::cost_func (optim.cpp:401-468) for up to four proposals at once: lane 16*g + i decodes proposal g
 // (x0..x2 hold that lane's proposal), builds the patch axes and the frame of view i; then each proposal is
 // evaluated in turn.  imgx = m_images replicated into every group of 16 lanes.
 DEV void sum_of_group(const WaveCtx& wc, unsigned okm, float val_l, int g, int sz, double& ans, int& denom) {
@@ -1066,41 +1071,39 @@ DEV double cost_of_group(const DParams& prm, const WaveCtx& wc, unsigned okm, fl
     if (denom < minimum - 1) return 2.0;
     return ans / (double)denom;
 }
-DEV void cost_func3(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int imgx, int n, bool three, float x0, float x1, float x2,
-                    double& f0, double& f1, double& f2, float* piv = nullptr, const ClsConst* cc = nullptr) {
+DEV void cost_func4(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int imgx, int n, bool four, float x0, float x1, float x2,
+                    double (&fv)[4], float* piv = nullptr, const ClsConst* cc = nullptr) {
     F4 coord, normal, px, py;
     decode(prm, rc, x0, x1, x2, coord, normal);
     get_paxes(prm, prm.views + rc.ref, coord, normal, px, py);
     const int sz = min(prm.tau, n);
     const int minimum = min(prm.minImageNum, sz);
     const int g = wc.lane >> 4, i = wc.lane & 15;
-    const Frame f = make_frame(prm, coord, px, py, normal, imgx, g < (three ? 3 : 1) && i < sz);
+    const Frame f = make_frame(prm, coord, px, py, normal, imgx, g < (four ? 4 : 1) && i < sz);
     float incc_l;
-    f1 = f2 = 2.0;
-    if (three) {
-        wc.evals += 3;
-        unsigned okm[3];
-        eval_steps3(prm, wc, *cc, f, sz, okm, incc_l);
+    fv[1] = fv[2] = fv[3] = 2.0;
+    if (four) {
+        wc.evals += 4;
+        unsigned okm[4];
+        eval_steps4(prm, wc, *cc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
-        // the three means: one fp64 division for all of them (lane j divides the sums of proposal j)
-        double a0, a1, a2;
-        int d0, d1, d2;
-        sum_of_group(wc, okm[0], val_l, 0, sz, a0, d0);
-        sum_of_group(wc, okm[1], val_l, 1, sz, a1, d1);
-        sum_of_group(wc, okm[2], val_l, 2, sz, a2, d2);
-        const double num = wc.lane == 1 ? a1 : (wc.lane == 2 ? a2 : a0);
-        const int den = wc.lane == 1 ? d1 : (wc.lane == 2 ? d2 : d0);
+        // the four means: one fp64 division for all of them (lane j divides the sums of proposal j)
+        double a[4];
+        int d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum_of_group(wc, okm[j], val_l, j, sz, a[j], d[j]);
+        const double num = wc.lane == 1 ? a[1] : (wc.lane == 2 ? a[2] : (wc.lane == 3 ? a[3] : a[0]));
+        const int den = wc.lane == 1 ? d[1] : (wc.lane == 2 ? d[2] : (wc.lane == 3 ? d[3] : d[0]));
         const double q = num / (double)den;
-        f0 = ((okm[0] & 1u) && d0 >= minimum - 1) ? rld(q, 0) : 2.0;
-        f1 = ((okm[1] & 1u) && d1 >= minimum - 1) ? rld(q, 1) : 2.0;
-        f2 = ((okm[2] & 1u) && d2 >= minimum - 1) ? rld(q, 2) : 2.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fv[j] = ((okm[j] & 1u) && d[j] >= minimum - 1) ? rld(q, j) : 2.0;
     } else {
         wc.evals += 1;
         unsigned okm[1];
         if (piv) eval_core<1, MVS_U1, true>(prm, wc, f, sz, okm, incc_l, piv);  // refinePatch's first evaluation: the view means become the pivots
         else eval_core<1, MVS_U1>(prm, wc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
-        f0 = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
+        fv[0] = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
     }
 }
 // Optim::refinePatch, optim.cpp:480-547, BOBYQA replaced by the halving random search
@@ -1120,30 +1123,35 @@ STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, u
     x[1] = fmaxf(fminf(x[1], amax), amin);
     x[2] = fmaxf(fminf(x[2], amax), amin);
     float bx0 = x[0], bx1 = x[1], bx2 = x[2];
-    double f0, f1, f2;
+    double fv[4];
     float piv[3] = {128.0f, 128.0f, 128.0f};  // view lanes: the mean colour of view k at the starting point
-    cost_func3(prm, wc, rc, imgx, c.nimg, false, bx0, bx1, bx2, f0, f1, f2, piv);
+    cost_func4(prm, wc, rc, imgx, c.nimg, false, bx0, bx1, bx2, fv, piv);
     __syncthreads();
     if (wc.lane < 16) mvs_dyn_lds4[MVS_PIVOT_LDS4 + wc.lane] = make_float4(piv[0], piv[1], piv[2], 0.0f);
     __syncthreads();
-    double fbest = f0;
+    double fbest = fv[0];
     const ClsConst cc = make_cls(prm, wc);
     float rd = prm.rd0, ra = prm.ra0;
-    const int g = wc.lane >> 4;  // this lane's proposal: 0 depth only, 1 angles only, 2 both (3: idle, computes proposal 2 again)
+    const int g = wc.lane >> 4;  // this lane's proposal: 0 depth only, 1 angles only, 2 both, 3 both mirrored about the step's start
     const uint32_t gj = (uint32_t)min(g, 2);
     for (int k = 0; k < prm.refine_steps; ++k) {
         const uint32_t draw = 16u + ((uint32_t)(k * 3) + gj) * 3u;
         const float u0 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 0);
         const float u1 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 1);
         const float u2 = 2.0f * rng_uniform(prm.seed, k0, k1, k2, k3, draw + 2);
-        const float cx0 = (gj == 1u) ? bx0 : fma_(u0, rd, bx0);
-        const float cx1 = (gj == 0u) ? bx1 : fmaxf(fminf(fma_(u1, ra, bx1), amax), amin);
-        const float cx2 = (gj == 0u) ? bx2 : fmaxf(fminf(fma_(u2, ra, bx2), amax), amin);
-        cost_func3(prm, wc, rc, imgx, c.nimg, true, cx0, cx1, cx2, f0, f1, f2, nullptr, &cc);
+        float cx0 = (gj == 1u) ? bx0 : fma_(u0, rd, bx0);
+        float cx1 = (gj == 0u) ? bx1 : fmaxf(fminf(fma_(u1, ra, bx1), amax), amin);
+        float cx2 = (gj == 0u) ? bx2 : fmaxf(fminf(fma_(u2, ra, bx2), amax), amin);
+        if (g == 3) {
+            cx0 = bx0 - (cx0 - bx0);
+            cx1 = fmaxf(fminf(bx1 - (cx1 - bx1), amax), amin);
+            cx2 = fmaxf(fminf(bx2 - (cx2 - bx2), amax), amin);
+        }
+        cost_func4(prm, wc, rc, imgx, c.nimg, true, cx0, cx1, cx2, fv, nullptr, &cc);
         int jb = 0;
-        double fstep = f0;
-        if (f1 < fstep) { fstep = f1; jb = 1; }
-        if (f2 < fstep) { fstep = f2; jb = 2; }
+        double fstep = fv[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) if (fv[j] < fstep) { fstep = fv[j]; jb = j; }
         if (fstep < fbest) { fbest = fstep; bx0 = rlf(cx0, 16 * jb); bx1 = rlf(cx1, 16 * jb); bx2 = rlf(cx2, 16 * jb); }
         rd *= 0.5f; ra *= 0.5f;
     }

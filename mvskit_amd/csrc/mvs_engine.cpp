@@ -432,7 +432,7 @@ void mvs_default_config(mvs_config* c) {  // Option::Option, option.cpp:19-33
     memset(c, 0, sizeof *c);
     c->level = 1; c->csize = 2; c->wsize = 7; c->minImageNum = 3; c->max_propag = 2;
     c->nccThreshold = 0.7f; c->maxAngleThreshold = (float)(10.0f * M_PI / 180.0f); c->quadThreshold = 2.5f;
-    c->depth = 1; c->seed = 1; c->refine_steps = 8; c->refine_rd0 = 4.0f; c->refine_ra0 = 4.0f; c->enable_check = 1;
+    c->depth = 1; c->seed = 1; c->refine_steps = 6; c->refine_rd0 = 4.0f; c->refine_ra0 = 4.0f; c->enable_check = 1;
     c->view_begin = 0; c->view_stride = 1; c->device = 0; c->max_patches = 0;
 }
 

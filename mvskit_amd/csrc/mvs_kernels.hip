@@ -833,9 +833,9 @@ __global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, co
         rc.dscale = c.dscale; rc.ascale = prm.ascaleConst;
         float x[3];
         encode(prm, rc, c.coord, c.normal, x);
-        double f, fu1, fu2;
-        cost_func3(prm, wc, rc, __shfl(c.img, wc.lane & 15), c.nimg, false, x[0], x[1], x[2], f, fu1, fu2);
-        if (wc.lane == 0) out_f[i] = (float)f;
+        double fv[4];
+        cost_func4(prm, wc, rc, __shfl(c.img, wc.lane & 15), c.nimg, false, x[0], x[1], x[2], fv);
+        if (wc.lane == 0) out_f[i] = (float)fv[0];
     }
 }
 
@@ -893,7 +893,8 @@ size_t mvsk_sweep_lds_bytes(const DParams& prm) {
     // in postProcess they lie behind the frame region (the evaluation that produces them publishes its frames there)
     const size_t texs = MVS_FRAME1_LDS_BYTES + ((size_t)MVS_LISTCAP * 3 * prm.wsz + (size_t)MVS_LISTCAP * (MVS_LISTCAP - 1) / 2) * sizeof(float);
     const size_t chk = (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float);                      // Optim::check hash set + rows
-    return texs > chk ? texs : chk;
+    const size_t need = texs > chk ? texs : chk;
+    return need > (size_t)MVS_FRAME_LDS_BYTES ? need : (size_t)MVS_FRAME_LDS_BYTES;  // the frames + pivots of a refinement step
 }
 void mvsk_sweep(const DParams& prm, const SweepArgs& a, hipStream_t st) {
     const int64_t nloc = a.job_hi - a.job_lo;

@@ -231,7 +231,7 @@ public:
     Filter m_filter;
     mvs_engine* m_engine = nullptr;  // Optim + the PatchManager grids live behind this handle
     unsigned m_seed = 1;
-    int m_refineSteps = 8;
+    int m_refineSteps = 6;
     int m_viewPropagation = 0;  // 1 = the branch propagate.cpp:110-120 keeps commented out
     bool m_writeFiles = true;
 

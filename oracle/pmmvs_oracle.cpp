@@ -912,21 +912,18 @@ void tex_stats_class16(const Scene& s, const Tex& tex, const float* piv, const f
             s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
             if (c0p) { s01 = fma_(r, c0p[0][q], s01); s01 = fma_(g, c0p[1][q], s01); s01 = fma_(b, c0p[2][q], s01); }
         }
-        if (c < L.rx) { /* the extras lane: its own sums from zero, then added to this lane's */
-            const int q = 16 * L.nj + c;
-            const float r = cp[0][q], g = cp[1][q], b = cp[2][q];
-            float x1r = 0.0f, x1g = 0.0f, x1b = 0.0f, x2 = 0.0f, x01 = 0.0f;
-            x1r += r; x1g += g; x1b += b;
-            x2 = fma_(r, r, x2); x2 = fma_(g, g, x2); x2 = fma_(b, b, x2);
-            if (c0p) { x01 = fma_(r, c0p[0][q], x01); x01 = fma_(g, c0p[1][q], x01); x01 = fma_(b, c0p[2][q], x01); }
-            s1r = fma_(x1r, 1.0f, s1r); s1g = fma_(x1g, 1.0f, s1g); s1b = fma_(x1b, 1.0f, s1b);
-            s2 = fma_(x2, 1.0f, s2); s01 = fma_(x01, 1.0f, s01);
-        }
         l1[0][c] = s1r; l1[1][c] = s1g; l1[2][c] = s1b; l2[c] = s2; l01[c] = s01;
     }
     for (int c = 0; c < 3; ++c) out.s1[c] = reduce_tree16(l1[c]);
     out.s2 = reduce_tree16(l2);
     out.s01 = reduce_tree16(l01);
+    for (int e = 0; e < L.rx; ++e) { /* the extras: added to the finished row sums, in sample order (the engine's frame lanes) */
+        const int q = 16 * L.nj + e;
+        const float r = cp[0][q], g = cp[1][q], b = cp[2][q];
+        out.s1[0] += r; out.s1[1] += g; out.s1[2] += b;
+        out.s2 = fma_(r, r, out.s2); out.s2 = fma_(g, g, out.s2); out.s2 = fma_(b, b, out.s2);
+        if (c0p) { out.s01 = fma_(r, c0p[0][q], out.s01); out.s01 = fma_(g, c0p[1][q], out.s01); out.s01 = fma_(b, c0p[2][q], out.s01); }
+    }
     if (cp_out) for (int c = 0; c < 3; ++c) for (int i = 0; i < 64; ++i) cp_out[c][i] = i < wsz ? cp[c][i] : 0.0f;
 }
 inline float cls_inv_msd(const Scene& s, const ClsSums& q, float* mean3) {
@@ -967,8 +964,8 @@ double cost_func_cls(const Scene& s, const RefineCtx& rc, const int* idx, int n,
 }
 
 /* Optim::refinePatch, optim.cpp:480-547.  The NLopt LN_BOBYQA call (511-524) is replaced by a
- * halving random search: K steps, per step 3 proposals around the step's start point
- * (depth only / angles only / both), the step's best is kept if it improves; ranges halve.
+ * halving random search: K steps, per step 4 proposals around the step's start point
+ * (depth only / angles only / both / both mirrored), the step's best is kept if it improves; ranges halve.
  * Same variables, same bounds (angles +-23.99999 units of pi/48, depth unbounded). */
 /* w_keep != nullptr (engine schedule inside propagatePatch): the weights go out and the final m_ncc is left to the first
  * constraintImages of postProcess, which samples the same textures anyway */
@@ -996,20 +993,26 @@ int refine_patch(const Scene& s, Patch& p, const uint32_t key[4], orc_counters* 
     double fbest = cost_func(s, rc, p.img, p.nimg, x, cnt, cls ? piv : nullptr);
     float rd = s.cfg.refine_rd0, ra = s.cfg.refine_ra0;
     for (int k = 0; k < s.cfg.refine_steps; ++k) {
-        float cand[3][3];
-        double f[3];
-        for (int j = 0; j < 3; ++j) {
-            const uint32_t draw = 16u + (uint32_t)(k * 3 + j) * 3u;
-            const float u0 = 2.0f * rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], draw + 0);
-            const float u1 = 2.0f * rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], draw + 1);
-            const float u2 = 2.0f * rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], draw + 2);
-            cand[j][0] = (j == 1) ? x[0] : fma_(u0, rd, x[0]);
-            cand[j][1] = (j == 0) ? x[1] : std::max(std::min(fma_(u1, ra, x[1]), amax), amin);
-            cand[j][2] = (j == 0) ? x[2] : std::max(std::min(fma_(u2, ra, x[2]), amax), amin);
+        float cand[4][3];
+        double f[4];
+        for (int j = 0; j < 4; ++j) {
+            if (j < 3) {
+                const uint32_t draw = 16u + (uint32_t)(k * 3 + j) * 3u;
+                const float u0 = 2.0f * rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], draw + 0);
+                const float u1 = 2.0f * rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], draw + 1);
+                const float u2 = 2.0f * rng_uniform(s.cfg.seed, key[0], key[1], key[2], key[3], draw + 2);
+                cand[j][0] = (j == 1) ? x[0] : fma_(u0, rd, x[0]);
+                cand[j][1] = (j == 0) ? x[1] : std::max(std::min(fma_(u1, ra, x[1]), amax), amin);
+                cand[j][2] = (j == 0) ? x[2] : std::max(std::min(fma_(u2, ra, x[2]), amax), amin);
+            } else { /* the "both" proposal mirrored about the step's start */
+                cand[3][0] = x[0] - (cand[2][0] - x[0]);
+                cand[3][1] = std::max(std::min(x[1] - (cand[2][1] - x[1]), amax), amin);
+                cand[3][2] = std::max(std::min(x[2] - (cand[2][2] - x[2]), amax), amin);
+            }
             f[j] = cls ? cost_func_cls(s, rc, p.img, p.nimg, cand[j], piv, cnt) : cost_func(s, rc, p.img, p.nimg, cand[j], cnt);
         }
         int jb = 0;
-        for (int j = 1; j < 3; ++j) if (f[j] < f[jb]) jb = j;
+        for (int j = 1; j < 4; ++j) if (f[j] < f[jb]) jb = j;
         if (f[jb] < fbest) { fbest = f[jb]; x[0] = cand[jb][0]; x[1] = cand[jb][1]; x[2] = cand[jb][2]; }
         rd *= 0.5f; ra *= 0.5f;
     }
@@ -1994,7 +1997,7 @@ void orc_default_config(orc_config* c) { /* Option::Option, option.cpp:19-33 */
     c->nviews = 0; c->level = 1; c->csize = 2; c->wsize = 7; c->minImageNum = 3; c->max_propag = 2;
     c->nccThreshold = 0.7f; c->maxAngleThreshold = (float)(10.0f * M_PI / 180.0f); c->quadThreshold = 2.5f;
     c->depth = 1; c->seed = 1; c->schedule = ORC_SCHEDULE_ENGINE; c->sum_mode = ORC_SUM_TREE64;
-    c->refine_steps = 8; c->refine_rd0 = 4.0f; c->refine_ra0 = 4.0f; c->enable_check = 1;
+    c->refine_steps = 6; c->refine_rd0 = 4.0f; c->refine_ra0 = 4.0f; c->enable_check = 1;
     c->view_begin = 0; c->view_stride = 1; c->nthreads = 1;
 }
 

@@ -58,7 +58,7 @@ typedef struct orc_config {
     uint32_t seed;
     int32_t schedule;     /* ORC_SCHEDULE_* */
     int32_t sum_mode;     /* ORC_SUM_* */
-    int32_t refine_steps; /* K halving steps, 3 proposals each: R = 1 + 3K evaluations */
+    int32_t refine_steps; /* K halving steps, 4 proposals each: R = 1 + 4K evaluations (default 6: 25) */
     float refine_rd0;     /* initial depth range, units of m_dscale */
     float refine_ra0;     /* initial angle range, units of pi/48 */
     int32_t enable_check; /* run Optim::check when depth >= 2 */
