@@ -355,12 +355,18 @@ DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, b
 
 struct __attribute__((packed, aligned(4))) Texel2 { uint32_t a, b; };
 
+// Per-lane constants of the class-lane sample layout: lane 16 r + c owns samples c, c + 16, c + 32 of the window its row
+// works on (a proposal in a refinement step, a view in a single evaluation).  A window of 16 k + 1 samples (7x7) has one
+// sample more, the "extra" xbase, which the lane that owns the sampling frame takes.
+struct ClsConst {
+    unsigned cs[3];  // per slot j: fx | fy << 8 | valid << 16
+    int fb;          // first lane of this lane's row (16 r)
+    int xbase, nx;   // the extra: sample xbase if nx == 1 (wave-uniform)
+};
 // Per-wave working state.
 struct WaveCtx {
     int lane;
-    bool sample_lane;   // lane < wsize*wsize
-    float fx, fy;       // this lane's sample column / row
-    float fm;           // 1 on sample lanes, 0 elsewhere
+    ClsConst cc;
     unsigned evals, view_evals;
 #ifdef MVS_STAGE_TIMING
     unsigned long long st_acc[8];  // diagnostic build: phase times, kept in registers and flushed once by the kernel
@@ -375,41 +381,8 @@ struct WaveCtx {
 #define WC_ADD(wc, k)
 #endif
 
-// Tail of Optim::getTex (sampling, optim.cpp:835-842 -> Image::getColor bilinear, image.cpp:447-472) and
-// Optim::normalize (optim.cpp:917-940) for frame lane e, split in two so that the loads of the next views are in
-// flight while the current ones are reduced, and branch-free so that the independent chains of the three proposals
-// of a refinement step interleave:
-//   tex_issue  : frame -> sample position -> the two 8-byte texel loads (nothing waits on them here)
-//   tex_centre : bilinear blend, channel means, centring
-struct Pending {
-    int ok;
-    Texel2 q0, q1;
-    float dx1, dy1;
-};
-DEV Pending tex_issue(const DParams& prm, const WaveCtx& wc, const Frame& f, int e) {
-    Pending p;
-    p.ok = rli(f.ok, e);
-    const int W = rli(f.w, e);
-    const float tlx = rlf(f.tlx, e), tly = rlf(f.tly, e), dxx = rlf(f.dxx, e), dxy = rlf(f.dxy, e), dyx = rlf(f.dyx, e), dyy = rlf(f.dyy, e);
-    // the address is rebuilt from two readlanes: say explicitly that it is global memory, or the loads become
-    // flat_load (which count on vmcnt AND lgkmcnt and cannot stay in flight across the reductions)
-    typedef const __attribute__((address_space(1))) uint32_t* GlobalTexels;
-    const unsigned long long base = ((unsigned long long)(unsigned)rli((int)f.img_hi, e) << 32) | (unsigned long long)(unsigned)rli((int)f.img_lo, e);
-    const float sx = wc.sample_lane ? fma_(dyx, wc.fy, fma_(dxx, wc.fx, tlx)) : 0.0f;
-    const float sy = wc.sample_lane ? fma_(dyy, wc.fy, fma_(dxy, wc.fx, tly)) : 0.0f;
-    const int lx = (int)sx, ly = (int)sy;
-    const unsigned long long a0 = base + 4ull * (unsigned long long)(unsigned)(ly * W + lx);
-    const GlobalTexels t0 = (GlobalTexels)a0, t1 = (GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)W);
-    p.q0.a = t0[0]; p.q0.b = t0[1];
-    p.q1.a = t1[0]; p.q1.b = t1[1];
-    p.dx1 = __builtin_amdgcn_fractf(sx); p.dy1 = __builtin_amdgcn_fractf(sy);  // == s - (float)(int)s for the non-negative positions sampled
-    return p;
-}
-// The same with the frames published in LDS (eval_core): three uniform-address ds_read_b128 (broadcasts, issued on
-// the LDS pipe) replace ten v_readlane_b32 on the VALU, which is the unit this kernel saturates.
-#ifndef MVS_FRAME_LDS
-#define MVS_FRAME_LDS 1
-#endif
+// The sampling frames of an evaluation are published in LDS (frames_publish) and read back by the sampling lanes: uniform
+// or per-row ds_read_b128 instead of ten v_readlane_b32 per sample on the vector ALU, the unit this kernel saturates.
 #define MVS_PIVOT_LDS4 192                         // float4 index of the per-view pivot colours (refinePatch, class lanes)
 #define MVS_FRAME_LDS_BYTES (64 * 48 + 16 * 16)    // frame lanes 0..63, 12 dwords each, + 16 pivots; the start of the kernel's dynamic LDS
 #define MVS_FRAME1_LDS_BYTES (48 * (MVS_LISTCAP > 16 ? MVS_LISTCAP : 16))  // what a single-proposal evaluation publishes there
@@ -424,167 +397,11 @@ DEV void frames_publish(const WaveCtx& wc, const Frame& f, int nlanes) {
     }
     __syncthreads();
 }
-DEV Pending tex_issue_lds(const DParams& prm, const WaveCtx& wc, int e) {
-    Pending p;
-    const float4* s = mvs_dyn_lds4 + 3 * e;
-    const float4 A = s[0], B = s[1];
-    const float2 Cc = *reinterpret_cast<const float2*>(s + 2);
-    p.ok = __float_as_int(B.w);
-    const int W = __float_as_int(B.z);
-    typedef const __attribute__((address_space(1))) uint32_t* GlobalTexels;
-    const unsigned long long base = ((unsigned long long)(unsigned)__float_as_int(Cc.y) << 32) | (unsigned long long)(unsigned)__float_as_int(Cc.x);
-    const float sx = wc.sample_lane ? fma_(B.x, wc.fy, fma_(A.z, wc.fx, A.x)) : 0.0f;
-    const float sy = wc.sample_lane ? fma_(B.y, wc.fy, fma_(A.w, wc.fx, A.y)) : 0.0f;
-    const int lx = (int)sx, ly = (int)sy;
-    const unsigned long long a0 = base + 4ull * (unsigned long long)(unsigned)(ly * W + lx);
-    const GlobalTexels t0 = (GlobalTexels)a0, t1 = (GlobalTexels)(a0 + 4ull * (unsigned long long)(unsigned)W);
-    p.q0.a = t0[0]; p.q0.b = t0[1];
-    p.q1.a = t1[0]; p.q1.b = t1[1];
-    p.dx1 = __builtin_amdgcn_fractf(sx); p.dy1 = __builtin_amdgcn_fractf(sy);  // == s - (float)(int)s for the non-negative positions sampled
-    return p;
-}
-// colour - mean on sample lanes (0 elsewhere)
-DEV void tex_centre(const DParams& prm, const WaveCtx& wc, const Pending& p, float& d0, float& d1, float& d2) {
-    const Texel2 q0 = p.q0, q1 = p.q1;
-    // lanes that own no sample were sent to texel (0,0) with dx1 = dy1 = 0; fm - dy1 makes their four weights 0, so
-    // their colours are 0 without a select, and fma(-mean, fm, colour) == colour - mean on sample lanes, 0 elsewhere
-    const float dx1 = p.dx1, dx0 = 1.0f - dx1, dy1 = p.dy1, dy0 = wc.fm - dy1;
-    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
-    float r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
-    float g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
-    float b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
-    float a0 = r, a1 = g, a2 = b;
-    wave_sum3(a0, a1, a2);
-    a0 *= prm.inv_sz; a1 *= prm.inv_sz; a2 *= prm.inv_sz;
-    d0 = fma_(-a0, wc.fm, r);
-    d1 = fma_(-a1, wc.fm, g);
-    d2 = fma_(-a2, wc.fm, b);
-}
-// the same, the channel means handed out as well (the pivots of refinePatch's class-lane evaluations)
-DEV void tex_centre_m(const DParams& prm, const WaveCtx& wc, const Pending& p, float& d0, float& d1, float& d2, float& a0, float& a1, float& a2) {
-    const Texel2 q0 = p.q0, q1 = p.q1;
-    const float dx1 = p.dx1, dx0 = 1.0f - dx1, dy1 = p.dy1, dy0 = wc.fm - dy1;
-    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
-    float r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
-    float g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
-    float b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
-    a0 = r; a1 = g; a2 = b;
-    wave_sum3(a0, a1, a2);
-    a0 *= prm.inv_sz; a1 *= prm.inv_sz; a2 *= prm.inv_sz;
-    d0 = fma_(-a0, wc.fm, r);
-    d1 = fma_(-a1, wc.fm, g);
-    d2 = fma_(-a2, wc.fm, b);
-}
-DEV float ssd_sum(float d0, float d1, float d2) { return wave_sum(fma_(d2, d2, fma_(d1, d1, d0 * d0))); }
-// Optim::dot, optim.cpp:601-609, on centred textures, before the scale factors
-DEV float tex_dot_sum(float a0, float a1, float a2, float b0, float b1, float b2) {
-    return wave_sum(fma_(a2, b2, fma_(a1, b1, a0 * b0)));
-}
 // second half of Optim::normalize, optim.cpp:932-939, on whatever lanes hold an ssd: 1 / msd
 DEV float inv_msd(const DParams& prm, float ssd) {
     float msd = sqrt_rn(ssd * prm.inv_3sz);
     if (msd == 0.0f) msd = 1.0f;
     return 1.0f / msd;
-}
-
-// Core of every texture evaluation: NP proposals (frame lanes 16*g + k, k < n) against their reference view k = 0.
-// Leaves in frame lane 16*g + k (k >= 1) the INCC of view k against the reference of proposal g,
-//     1 - (sum(d0*dk) * (inv0 * invk)) / (3*sz)              (Optim::dot on normalised textures, optim.cpp:601-609)
-// and in okm[g] the bit mask of views that were sampled.  One sqrt/division sequence serves all NP*n views.
-// NP*U independent sampling chains are kept in flight per step (U consecutive views of each proposal), and the
-// loads of the next step are issued before the current step is reduced.
-// PIV (single proposal only): piv[0..2] receive, in view lane k, the channel means of view k (128 for a view that was
-// not sampled) -- the pivots of the class-lane evaluations that follow in refinePatch.
-// texs != nullptr (single proposal only): the centred texture of view k goes to LDS, texs[(3 k + channel) * tstride + sample],
-// and *ssd_out receives, in view lane k, its sum of squares -- what Optim::setRefImage needs of these very views when it
-// follows (postProcess), so that it does not sample them a second time.
-template <int NP, int U, bool PIV = false>
-DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[NP], float& incc_l, float* piv = nullptr,
-                   float* texs = nullptr, int tstride = 0, float* ssd_out = nullptr) {
-    constexpr int NS = NP * U;
-    static_assert(!PIV || NP == 1, "pivots come from a single-proposal evaluation");
-    float d0[NP][3];
-    float ssd_l = 1.0f, dot_l = 0.0f;
-    Pending pr[NP], pn[NS];
-    unsigned okv[NP];  // per-lane copies of the (uniform) masks: the ok flags come back from LDS in vector registers
-#if MVS_FRAME_LDS
-    frames_publish(wc, f, NP == 1 ? (MVS_LISTCAP > 16 ? MVS_LISTCAP : 16) : 16 * NP);  // a single proposal may span a whole list (setINCCs), three proposals span tau <= 16 views each
-#define TEX_ISSUE(e) tex_issue_lds(prm, wc, e)
-#else
-#define TEX_ISSUE(e) tex_issue(prm, wc, f, e)
-#endif
-#pragma unroll
-    for (int g = 0; g < NP; ++g) { okv[g] = 0u; pr[g] = TEX_ISSUE(16 * g); }
-#pragma unroll
-    for (int g = 0; g < NP; ++g)
-#pragma unroll
-        for (int u = 0; u < U; ++u) pn[g * U + u] = TEX_ISSUE(16 * g + min(1 + u, n - 1));
-#pragma unroll
-    for (int g = 0; g < NP; ++g) {
-        if (PIV) {
-            float a0, a1, a2;
-            tex_centre_m(prm, wc, pr[g], d0[g][0], d0[g][1], d0[g][2], a0, a1, a2);
-            if (wc.lane == 0) { piv[0] = pr[g].ok ? a0 : 128.0f; piv[1] = pr[g].ok ? a1 : 128.0f; piv[2] = pr[g].ok ? a2 : 128.0f; }
-        } else
-        tex_centre(prm, wc, pr[g], d0[g][0], d0[g][1], d0[g][2]);
-        const float s = ssd_sum(d0[g][0], d0[g][1], d0[g][2]);
-        okv[g] |= (unsigned)pr[g].ok;
-        if (wc.lane == 16 * g) ssd_l = s;
-        if (NP == 1 && texs && wc.sample_lane) {
-            texs[0 * tstride + wc.lane] = d0[g][0]; texs[1 * tstride + wc.lane] = d0[g][1]; texs[2 * tstride + wc.lane] = d0[g][2];
-        }
-    }
-    for (int k0 = 1; k0 < n; k0 += U) {
-        Pending p[NS];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) p[q] = pn[q];
-        if (k0 + U < n) {
-#pragma unroll
-            for (int g = 0; g < NP; ++g)
-#pragma unroll
-                for (int u = 0; u < U; ++u) pn[g * U + u] = TEX_ISSUE(16 * g + min(k0 + U + u, n - 1));
-        }
-#pragma unroll
-        for (int g = 0; g < NP; ++g)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = k0 + u;
-                float e0, e1, e2;
-                if (PIV) {
-                    float a0, a1, a2;
-                    tex_centre_m(prm, wc, p[g * U + u], e0, e1, e2, a0, a1, a2);
-                    const bool okk = p[g * U + u].ok != 0;
-                    if (k < n && wc.lane == k) { piv[0] = okk ? a0 : 128.0f; piv[1] = okk ? a1 : 128.0f; piv[2] = okk ? a2 : 128.0f; }
-                } else
-                tex_centre(prm, wc, p[g * U + u], e0, e1, e2);
-                float s = fma_(e2, e2, fma_(e1, e1, e0 * e0));                        // ssd_sum
-                float dt = fma_(d0[g][2], e2, fma_(d0[g][1], e1, d0[g][0] * e0));     // tex_dot_sum
-                wave_sum2(s, dt);
-                if (k < n) {
-                    okv[g] |= (unsigned)p[g * U + u].ok << k;
-                    if (wc.lane == 16 * g + k) { ssd_l = s; dot_l = dt; }
-                    if (NP == 1 && texs && wc.sample_lane) {
-                        texs[(3 * k + 0) * tstride + wc.lane] = e0; texs[(3 * k + 1) * tstride + wc.lane] = e1; texs[(3 * k + 2) * tstride + wc.lane] = e2;
-                    }
-                }
-            }
-    }
-    // the metric's work count: views that sampled; nothing counts when the reference view itself was rejected
-    // (Optim::cost_func / computeINCC / setINCCs return before looking at the others, optim.cpp:448,657,725)
-#undef TEX_ISSUE
-#pragma unroll
-    for (int g = 0; g < NP; ++g) okm[g] = (unsigned)rfl((int)okv[g]);
-#pragma unroll
-    for (int g = 0; g < NP; ++g) wc.view_evals += (okm[g] & 1u) ? (unsigned)__popc(okm[g]) : 0u;
-    if (NP == 1 && ssd_out) *ssd_out = ssd_l;
-    const float inv_l = inv_msd(prm, ssd_l);
-    float inv0_l = rlf(inv_l, 0);
-    if (NP > 1) {
-        const int g = wc.lane >> 4;
-        const float i1 = rlf(inv_l, 16), i2 = rlf(inv_l, 32);
-        inv0_l = g == 1 ? i1 : (g == 2 ? i2 : inv0_l);
-    }
-    incc_l = 1.0f - (dot_l * (inv0_l * inv_l)) * prm.inv_3sz;
 }
 
 // ------------------------------------------------------------------ class-lane evaluation (the four proposals of a refinement step)
@@ -601,25 +418,19 @@ DEV void eval_core(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsig
 // mean m = S1 / n;  ssd = max(S2 - S1 . m, 0);  dot = S01 - S1 . m0;  INCC = 1 - dot (inv0 inv) / 3n.  The sums run
 // j-ascending inside a lane, the row tree pairs lanes 1, 2, 4, 8 apart, the extras are added last, in sample order.
 struct ClsPend { Texel2 q0, q1; float dx1, dy1; };
-// Per-lane constants of the class-lane layout: lane 16 g + c owns samples c, c + 16, c + 32 of proposal g.
-struct ClsConst {
-    unsigned cs[3];  // per iteration j: fx | fy << 8 | valid << 16
-    int fb;          // first frame lane of this lane's proposal (16 g)
-    int xbase, nx;   // the extras: samples xbase .. xbase + nx - 1 (wave-uniform)
-};
-DEV ClsConst make_cls(const DParams& prm, const WaveCtx& wc) {
+DEV ClsConst make_cls(const DParams& prm, int lane) {
     ClsConst cc;
     const int wsz = prm.wsz, nj = wsz >> 4, rem = wsz & 15;
-    const int rx = rem <= 5 ? rem : 0, njx = nj + (rem > 5 ? 1 : 0);
-    const int row = wc.lane >> 4, c = wc.lane & 15;
+    const int njx = nj + (rem > 1 ? 1 : 0), lim = rem > 1 ? wsz : 16 * nj;
+    const int row = lane >> 4, c = lane & 15;
     cc.fb = 16 * row;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int s = c + 16 * j;
-        const bool valid = j < njx && s < (rem > 5 ? wsz : 16 * nj);
-        cc.cs[j] = valid ? (unsigned)(s % prm.wsize) | ((unsigned)(s / prm.wsize) << 8) | (1u << 16) : 0u;
+        const int q = c + 16 * j;
+        const bool valid = j < njx && q < lim;
+        cc.cs[j] = valid ? (unsigned)(q % prm.wsize) | ((unsigned)(q / prm.wsize) << 8) | (1u << 16) : 0u;
     }
-    cc.xbase = 16 * nj; cc.nx = rx;
+    cc.xbase = 16 * nj; cc.nx = rem == 1 ? 1 : 0;
     return cc;
 }
 DEV float cvt_ub0(unsigned x) { return (float)(x & 255u); }
@@ -736,8 +547,8 @@ DEV void eval_steps4(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const 
         ClsFrame fr;
         fr.tlx = f.tlx; fr.tly = f.tly; fr.dxx = f.dxx; fr.dxy = f.dxy; fr.dyx = f.dyx; fr.dyy = f.dyy; fr.w = f.w;
         fr.base = ((unsigned long long)f.img_hi << 32) | (unsigned long long)f.img_lo;
-        for (int e = 0; e < cc.nx; ++e) {
-            const int q = cc.xbase + e;
+        {
+            const int q = cc.xbase;
             const unsigned cs = (unsigned)(q % prm.wsize) | ((unsigned)(q / prm.wsize) << 8) | (1u << 16);
             const ClsPend pe = cls_issue(fr, cs);
             float r, g, b;
@@ -755,6 +566,140 @@ DEV void eval_steps4(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const 
     const float m0r = bperm_f(a0, m_r), m0g = bperm_f(a0, m_g), m0b = bperm_f(a0, m_b), inv0 = bperm_f(a0, inv_l);
     const float dot = P01 - fma_(P1b, m0b, fma_(P1g, m0g, P1r * m0r));
     incc_l = 1.0f - (dot * (inv0 * inv_l)) * prm.inv_3sz;
+}
+
+// ------------------------------------------------------------------ class-lane evaluation of ONE patch against n views
+// Every single evaluation (computeINCC, setINCCs, constraintImages, the first cost_func of refinePatch, setRefImage's
+// textures): frame lane k < n holds the sampling frame of view k.  The four 16-lane rows take four views at a time --
+// row r of round t samples view 4 t + r, lane 16 r + c its samples c, c + 16, c + 32 -- and the frame lanes take the
+// extra sample of their own view beforehand.  Optim::normalize and Optim::dot in two passes as the reference has them:
+// channel means (lane sums, row tree, extra), centring, then sum of squares and product with the centred reference
+// texture (same order).  The reference view is view 0 = row 0 of round 0; its centred colours reach the other rows
+// through ds_bpermute once, after which every row holds them for the samples it owns.
+// The per-view scalars of view v are formed in lane 16 (v & 3) + (v >> 2) and moved to view lane v at the end.
+// Leaves in view lane k >= 1 the INCC of view k against the reference view, okm[0] = views that sampled.
+// PIV: piv[0..2] receive, in view lane k, the channel means of view k (128 for a view that was not sampled) -- the
+// pivots of the class-lane steps that follow in refinePatch.
+// texs != nullptr: the centred texture of view k goes to LDS, texs[(3 k + channel) * tstride + sample], and *ssd_out
+// receives, in view lane k, its sum of squares -- what Optim::setRefImage needs.
+DEV void cls_raw(const ClsPend& p, unsigned cs, float& r, float& g, float& b) {  // bilinear blend; 0 on a slot without a sample
+    const Texel2 q0 = p.q0, q1 = p.q1;
+    const float fm = cvt_ub2(cs);
+    const float dx1 = p.dx1 * fm, dx0 = fm - dx1, dy1 = p.dy1, dy0 = 1.0f - dy1;
+    const float f00 = dx0 * dy0, f01 = dx0 * dy1, f10 = dx1 * dy0, f11 = dx1 * dy1;
+    r = fma_((float)(q1.b & 255u), f11, fma_((float)(q0.b & 255u), f10, fma_((float)(q1.a & 255u), f01, (float)(q0.a & 255u) * f00)));
+    g = fma_((float)((q1.b >> 8) & 255u), f11, fma_((float)((q0.b >> 8) & 255u), f10, fma_((float)((q1.a >> 8) & 255u), f01, (float)((q0.a >> 8) & 255u) * f00)));
+    b = fma_((float)((q1.b >> 16) & 255u), f11, fma_((float)((q0.b >> 16) & 255u), f10, fma_((float)((q1.a >> 16) & 255u), f01, (float)((q0.a >> 16) & 255u) * f00)));
+}
+#define MVS_ROW_STEP3(C) { const float t0 = dpp0_f<C>(s1r), t1 = dpp0_f<C>(s1g), t2 = dpp0_f<C>(s1b); s1r = s1r + t0; s1g = s1g + t1; s1b = s1b + t2; }
+#define MVS_ROW_STEP2(C) { const float t0 = dpp0_f<C>(sq), t1 = dpp0_f<C>(dt); sq = sq + t0; dt = dt + t1; }
+#ifndef MVS_EV_PREFETCH
+#define MVS_EV_PREFETCH 1
+#endif
+template <bool PIV = false>
+DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[1], float& incc_l, float* piv = nullptr,
+                    float* texs = nullptr, int tstride = 0, float* ssd_out = nullptr) {
+    const ClsConst& cc = wc.cc;
+    frames_publish(wc, f, MVS_LISTCAP > 16 ? MVS_LISTCAP : 16);
+    okm[0] = (unsigned)(ballot(f.ok != 0) & 0xffffffffull);  // a frame is only ever valid on a lane < n
+    wc.view_evals += (okm[0] & 1u) ? (unsigned)__popc(okm[0]) : 0u;
+    const int row = wc.lane >> 4, lc = wc.lane & 15;
+    // the extra sample of view k in frame lane k (raw colours): its loads go out first, the first round's behind them
+    float fxr = 0.0f, fxg = 0.0f, fxb = 0.0f;
+    unsigned xcs = 0u;
+    ClsPend pe;
+    if (cc.nx > 0) {
+        ClsFrame fr;
+        fr.tlx = f.tlx; fr.tly = f.tly; fr.dxx = f.dxx; fr.dxy = f.dxy; fr.dyx = f.dyx; fr.dyy = f.dyy; fr.w = f.w;
+        fr.base = ((unsigned long long)f.img_hi << 32) | (unsigned long long)f.img_lo;
+        xcs = (unsigned)(cc.xbase % prm.wsize) | ((unsigned)(cc.xbase / prm.wsize) << 8) | (1u << 16);
+        pe = cls_issue(fr, xcs);
+    }
+    float d0[3][3], d0x[3] = {0.0f, 0.0f, 0.0f};
+    float ssd_l = 1.0f, dot_l = 0.0f, mr_l = 128.0f, mg_l = 128.0f, mb_l = 128.0f;
+    ClsPend pend[3];
+    {
+        const ClsFrame fr = cls_frame(min(row, n - 1));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pend[j] = cls_issue(fr, cls_opaque(cc.cs[j]));
+    }
+    if (cc.nx > 0) cls_raw(pe, xcs, fxr, fxg, fxb);
+    const int rounds = (n + 3) >> 2;
+    for (int t = 0; t < rounds; ++t) {
+        const int v = 4 * t + row, vq = min(v, n - 1);
+#if MVS_EV_PREFETCH
+        const ClsFrame fn = cls_frame(min(v + 4, n - 1));
+#endif
+        float cr[3], cg[3], cb[3];
+        float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned cs = cls_opaque(cc.cs[j]);
+            cls_raw(pend[j], cs, cr[j], cg[j], cb[j]);
+#if MVS_EV_PREFETCH
+            pend[j] = cls_issue(fn, cs);
+#endif
+            s1r += cr[j]; s1g += cg[j]; s1b += cb[j];
+        }
+        MVS_ROW_STEP3(0xB1) MVS_ROW_STEP3(0x4E) MVS_ROW_STEP3(0x141) MVS_ROW_STEP3(0x140)
+        float xr = 0.0f, xg = 0.0f, xb = 0.0f;
+        if (cc.nx > 0) {
+            xr = bperm_f(4 * vq, fxr); xg = bperm_f(4 * vq, fxg); xb = bperm_f(4 * vq, fxb);
+            s1r += xr; s1g += xg; s1b += xb;
+        }
+        const float mr = s1r * prm.inv_sz, mg = s1g * prm.inv_sz, mb = s1b * prm.inv_sz;
+        float er[3], eg[3], eb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float fm = cvt_ub2(cls_opaque(cc.cs[j]));
+            er[j] = fma_(-mr, fm, cr[j]); eg[j] = fma_(-mg, fm, cg[j]); eb[j] = fma_(-mb, fm, cb[j]);
+        }
+        const float exr = xr - mr, exg = xg - mg, exb = xb - mb;
+        if (t == 0) {  // the centred reference texture: from row 0 to every row
+            const int a0 = 4 * lc;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { d0[j][0] = bperm_f(a0, er[j]); d0[j][1] = bperm_f(a0, eg[j]); d0[j][2] = bperm_f(a0, eb[j]); }
+            if (cc.nx > 0) { d0x[0] = bperm_f(0, exr); d0x[1] = bperm_f(0, exg); d0x[2] = bperm_f(0, exb); }
+        }
+        float sq = 0.0f, dt = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            sq += fma_(eb[j], eb[j], fma_(eg[j], eg[j], er[j] * er[j]));
+            dt += fma_(d0[j][2], eb[j], fma_(d0[j][1], eg[j], d0[j][0] * er[j]));
+        }
+        MVS_ROW_STEP2(0xB1) MVS_ROW_STEP2(0x4E) MVS_ROW_STEP2(0x141) MVS_ROW_STEP2(0x140)
+        if (cc.nx > 0) {
+            sq += fma_(exb, exb, fma_(exg, exg, exr * exr));
+            dt += fma_(d0x[2], exb, fma_(d0x[1], exg, d0x[0] * exr));
+        }
+        if (lc == t) { ssd_l = sq; dot_l = dt; if (PIV) { mr_l = mr; mg_l = mg; mb_l = mb; } }
+#if !MVS_EV_PREFETCH
+        if (t + 1 < rounds) {
+            const ClsFrame fn = cls_frame(min(v + 4, n - 1));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pend[j] = cls_issue(fn, cls_opaque(cc.cs[j]));
+        }
+#endif
+        if (texs && v < n) {
+            float* tv = texs + (3 * v) * tstride;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (cc.cs[j] >> 16) { const int q = lc + 16 * j; tv[q] = er[j]; tv[tstride + q] = eg[j]; tv[2 * tstride + q] = eb[j]; }
+            if (cc.nx > 0 && lc == 0) { tv[cc.xbase] = exr; tv[tstride + cc.xbase] = exg; tv[2 * tstride + cc.xbase] = exb; }
+        }
+    }
+    // lane 16 (v & 3) + (v >> 2): 1 / msd and the INCC of view v; then to view lane v
+    const float inv_l = inv_msd(prm, ssd_l);
+    const float inv0 = rlf(inv_l, 0);
+    const float incc_v = 1.0f - (dot_l * (inv0 * inv_l)) * prm.inv_3sz;
+    const int src = 4 * (16 * (wc.lane & 3) + ((wc.lane >> 2) & 15));
+    incc_l = bperm_f(src, incc_v);
+    if (ssd_out) *ssd_out = bperm_f(src, ssd_l);
+    if (PIV) {
+        const bool okk = (okm[0] >> (wc.lane & 31)) & 1u;
+        const float a0 = bperm_f(src, mr_l), a1 = bperm_f(src, mg_l), a2 = bperm_f(src, mb_l);
+        piv[0] = (wc.lane < 32 && okk) ? a0 : 128.0f; piv[1] = (wc.lane < 32 && okk) ? a1 : 128.0f; piv[2] = (wc.lane < 32 && okk) ? a2 : 128.0f;
+    }
 }
 
 // ------------------------------------------------------------------ candidate patch (registers)
@@ -799,7 +744,7 @@ DEV float compute_incc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < sz);
     unsigned okm[1];
     float incc_l;
-    eval_core<1, MVS_U1>(prm, wc, f, sz, okm, incc_l);
+    eval_views(prm, wc, f, sz, okm, incc_l);
     if (!(okm[0] & 1u)) return 2.0f;
     const float val_l = robust ? robustincc(incc_l) : incc_l;
     float score = 0.0f, total = 0.0f;
@@ -842,7 +787,7 @@ DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int im
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < n);
     unsigned okm[1];
     float incc_l;
-    eval_core<1, MVS_U1>(prm, wc, f, n, okm, incc_l, nullptr, texs, tstride, ssd_out);
+    eval_views(prm, wc, f, n, okm, incc_l, nullptr, texs, tstride, ssd_out);
     if (okm_out) *okm_out = okm[0];
     if (!(okm[0] & 1u)) return 2.0f;
     float incc = robust ? robustincc(incc_l) : incc_l;
@@ -1100,8 +1045,8 @@ DEV void cost_func4(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
     } else {
         wc.evals += 1;
         unsigned okm[1];
-        if (piv) eval_core<1, MVS_U1, true>(prm, wc, f, sz, okm, incc_l, piv);  // refinePatch's first evaluation: the view means become the pivots
-        else eval_core<1, MVS_U1>(prm, wc, f, sz, okm, incc_l);
+        if (piv) eval_views<true>(prm, wc, f, sz, okm, incc_l, piv);  // refinePatch's first evaluation: the view means become the pivots
+        else eval_views(prm, wc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
         fv[0] = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
     }
@@ -1130,7 +1075,7 @@ STAGE void refine_patch(const DParams& prm, WaveCtx& wc, Cand& c, uint32_t k0, u
     if (wc.lane < 16) mvs_dyn_lds4[MVS_PIVOT_LDS4 + wc.lane] = make_float4(piv[0], piv[1], piv[2], 0.0f);
     __syncthreads();
     double fbest = fv[0];
-    const ClsConst cc = make_cls(prm, wc);
+    const ClsConst cc = wc.cc;
     float rd = prm.rd0, ra = prm.ra0;
     const int g = wc.lane >> 4;  // this lane's proposal: 0 depth only, 1 angles only, 2 both, 3 both mirrored about the step's start
     const uint32_t gj = (uint32_t)min(g, 2);
@@ -1206,39 +1151,13 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     wc.evals++;
     const Frame f = make_frame(prm, c.coord, px, py, c.normal, c.img, wc.lane < n);
     WC_ADD(wc, 1)
-    __syncthreads();
-    // centred textures to LDS (three views in flight per step), their ssd to view lanes
-    {
-        Pending pn[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) pn[u] = tex_issue(prm, wc, f, min(u, n - 1));
-        for (int i0 = 0; i0 < n; i0 += 3) {
-            Pending p[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) p[u] = pn[u];
-            if (i0 + 3 < n) {
-#pragma unroll
-                for (int u = 0; u < 3; ++u) pn[u] = tex_issue(prm, wc, f, min(i0 + 3 + u, n - 1));
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int i = i0 + u;
-                float t0, t1, t2;
-                tex_centre(prm, wc, p[u], t0, t1, t2);
-                const float s = ssd_sum(t0, t1, t2);
-                if (i < n) {
-                    okmask |= (unsigned)p[u].ok << i;
-                    wc.view_evals += (unsigned)p[u].ok;
-                    if (wc.lane == i) ssd_l = s;
-                    if (wc.sample_lane) {
-                        texs[(i * 3 + 0) * tstride + wc.lane] = t0;
-                        texs[(i * 3 + 1) * tstride + wc.lane] = t1;
-                        texs[(i * 3 + 2) * tstride + wc.lane] = t2;
-                    }
-                }
-            }
-        }
-    }
+    // centred textures to LDS behind the frames this evaluation publishes, their ssd to view lanes
+    texs += MVS_FRAME1_LDS_BYTES / 4;
+    unsigned okm1[1];
+    float incc_unused;
+    eval_views(prm, wc, f, n, okm1, incc_unused, nullptr, texs, tstride, &ssd_l);
+    okmask = okm1[0];
+    if (!(okmask & 1u)) wc.view_evals += (unsigned)__popc(okmask);  // Optim::setINCCs (matrix) samples every view, whatever the first one did
     }
     const float inv_l = inv_msd(prm, ssd_l);
     WC_ADD(wc, 2)
@@ -1389,10 +1308,7 @@ DEV void store_cand(DPatch* p, const WaveCtx& wc, const Cand& c, int flags, int 
 DEV WaveCtx make_wave_ctx(const DParams& prm) {
     WaveCtx wc;
     wc.lane = lane_id();
-    wc.sample_lane = wc.lane < prm.wsz;
-    wc.fm = wc.sample_lane ? 1.0f : 0.0f;
-    wc.fx = (float)(wc.lane % prm.wsize);
-    wc.fy = (float)(wc.lane / prm.wsize);
+    wc.cc = make_cls(prm, wc.lane);
     wc.evals = 0; wc.view_evals = 0;
 #ifdef MVS_STAGE_TIMING
     for (int k = 0; k < 8; ++k) wc.st_acc[k] = 0;

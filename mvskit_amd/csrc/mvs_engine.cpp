@@ -749,6 +749,7 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hc.stage[k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
         static const char* nm2[4] = {"gain", "search", "sort", "quad"};
         for (int k = 0; k < 4; ++k) fprintf(stderr, " %s %.1f%%", nm2[k], 100.0 * (double)hc.stage[8 + k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
+        fprintf(stderr, " setRefImage pairs %.1f%% choice %.1f%%", 100.0 * (double)hc.stage[14] / (double)(hc.stage[0] ? hc.stage[0] : 1), 100.0 * (double)hc.stage[15] / (double)(hc.stage[0] ? hc.stage[0] : 1));
         fprintf(stderr, "  (wave cycles %.3e; max visited %llu, max neighbours %llu)\n", (double)hc.stage[0], hc.stage[12], hc.stage[13]);
     }
 #endif

@@ -477,6 +477,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
         st_acc[0] = ST_NOW() - st_begin;
         for (int k = 0; k < 12; ++k) if (st_acc[k]) atomicAdd(&C->stage[k], st_acc[k]);
         atomicMax(&C->stage[12], st_acc[12]); atomicMax(&C->stage[13], st_acc[13]);
+        atomicAdd(&C->stage[14], wc.st_acc[3]); atomicAdd(&C->stage[15], wc.st_acc[4]);  // inside postProcess: setRefImage's pair sums and choice
 #endif
     }
 }

@@ -397,8 +397,45 @@ inline float reduce_tree64(const float* a) { /* wave64 butterfly, offsets 1,2,4,
     }
     return b[0];
 }
+/* The engine's sample layout ("class lanes"): lane c of a 16-lane row owns samples c, c + 16, c + 32 of a window (njx slots,
+ * the last one partly filled); a window of 16 k + 1 samples (7x7) leaves one "extra" sample, taken by the lane that
+ * owns the view's sampling frame and added last.  Every sum over the samples of a window runs in this order in the
+ * engine arithmetic: inside a lane slot-ascending, then one DPP row tree (partners 1, 2, 4, 8 apart), then the extra. */
+struct ClsLayout { int nj, rem, rx, njx, nl, lim; };
+inline ClsLayout cls_layout_of(int wsize) {
+    ClsLayout L;
+    const int wsz = wsize * wsize;
+    L.nj = wsz >> 4; L.rem = wsz & 15;
+    L.rx = L.rem == 1 ? 1 : 0;
+    L.njx = L.nj + (L.rem > 1 ? 1 : 0);
+    L.nl = std::max(L.njx, L.rx ? 1 : 0);
+    L.lim = L.rem > 1 ? wsz : 16 * L.nj;
+    return L;
+}
+inline ClsLayout cls_layout(const Scene& s) { return cls_layout_of(s.cfg.wsize); }
+inline float reduce_tree16(const float* a) { /* one DPP row: partners 1, 2, 4, 8 apart */
+    float b[16], t[16];
+    for (int i = 0; i < 16; ++i) b[i] = a[i];
+    for (int off = 1; off < 16; off <<= 1) {
+        for (int i = 0; i < 16; ++i) t[i] = b[i] + b[i ^ off];
+        for (int i = 0; i < 16; ++i) b[i] = t[i];
+    }
+    return b[0];
+}
+inline float reduce_cls16(const Scene& s, const float* a) {
+    const ClsLayout L = cls_layout(s);
+    float lane[16];
+    for (int c = 0; c < 16; ++c) {
+        float t = 0.0f;
+        for (int j = 0; j < L.njx; ++j) { const int q = c + 16 * j; if (q < L.lim) t += a[q]; }
+        lane[c] = t;
+    }
+    float r = reduce_tree16(lane);
+    for (int e = 0; e < L.rx; ++e) r += a[16 * L.nj + e];
+    return r;
+}
 inline float reduce(const Scene& s, const float* a64, int n) {
-    return s.cfg.sum_mode == ORC_SUM_TREE64 ? reduce_tree64(a64) : reduce_seq(a64, n);
+    return s.cfg.sum_mode == ORC_SUM_TREE64 ? reduce_cls16(s, a64) : reduce_seq(a64, n);
 }
 
 /* ------------------------------------------------------------------ Optim (pmmvps/optim.cpp) */
@@ -873,25 +910,6 @@ double cost_func(const Scene& s, const RefineCtx& rc, const int* idx, int n, con
  *     S1 = sum c',  S2 = sum |c'|^2,  S01 = sum c' . c0'   (c0' = the reference view's colour of the same sample)
  *     mean m = S1 / n,  ssd = max(S2 - S1 . m, 0),  dot = S01 - S1 . m0,  INCC = 1 - dot (inv0 inv) / 3n
  * -- the same quantities (sum (c - mean)^2 = sum c^2 - n mean^2), the pivot keeping the squares small enough for fp32. */
-struct ClsLayout { int nj, rem, rx, njx, nl; };
-inline ClsLayout cls_layout(const Scene& s) {
-    ClsLayout L;
-    const int wsz = s.cfg.wsize * s.cfg.wsize;
-    L.nj = wsz >> 4; L.rem = wsz & 15;
-    L.rx = L.rem <= 5 ? L.rem : 0;
-    L.njx = L.nj + (L.rem > 5 ? 1 : 0);
-    L.nl = std::max(L.njx, L.rx ? 1 : 0);
-    return L;
-}
-inline float reduce_tree16(const float* a) { /* one DPP row: partners 1, 2, 4, 8 apart */
-    float b[16], t[16];
-    for (int i = 0; i < 16; ++i) b[i] = a[i];
-    for (int off = 1; off < 16; off <<= 1) {
-        for (int i = 0; i < 16; ++i) t[i] = b[i] + b[i ^ off];
-        for (int i = 0; i < 16; ++i) b[i] = t[i];
-    }
-    return b[0];
-}
 struct ClsSums { float s1[3], s2, s01; };
 /* tex: raw colours of one view; piv: its pivot; c0p: the reference view's c' per sample (nullptr for the reference view
  * itself); cp_out: this view's c' per sample */
@@ -901,7 +919,7 @@ void tex_stats_class16(const Scene& s, const Tex& tex, const float* piv, const f
     float cp[3][64];
     for (int i = 0; i < wsz; ++i) for (int c = 0; c < 3; ++c) cp[c][i] = fma_(-piv[c], 1.0f, tex.c[c][i]);
     float l1[3][16], l2[16], l01[16];
-    const int lim = L.rem > 5 ? wsz : 16 * L.nj;
+    const int lim = L.lim;
     for (int c = 0; c < 16; ++c) {
         float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f, s2 = 0.0f, s01 = 0.0f;
         for (int j = 0; j < L.njx; ++j) {
