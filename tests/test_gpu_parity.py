@@ -274,6 +274,15 @@ def test_variant_wsize5_csize1(small_plane_scene):
     assert c["patches"] > 300
 
 
+@pytest.mark.parametrize("wsize", [6, 4, 3, 2])
+def test_variant_window_sizes(small_plane_scene, wsize):
+    """Every window size the class-lane layout deals differently: 36 = two full slots + a partly filled third, 16 = one slot,
+    9 and 4 = one partly filled slot (7x7 = three slots + the extra sample and 5x5 = two slots are covered above)."""
+    seeds = synth.make_seeds(small_plane_scene, stride=4, seed=14)
+    c = _one_iteration_matches(small_plane_scene, seeds, minImageNum=2, wsize=wsize, seed=6)
+    assert c["patches"] > 300
+
+
 def test_variant_csize3(small_plane_scene):
     seeds = synth.make_seeds(small_plane_scene, csize=3, stride=2, seed=6)
     c = _one_iteration_matches(small_plane_scene, seeds, minImageNum=2, csize=3, seed=1)
