@@ -27,9 +27,6 @@ struct F4 { float x, y, z, w; };
 #define DEV __device__ __forceinline__
 // The stages around the refinement loop can be compiled as real calls (MVS_OUTLINE=1): their register live ranges
 // then do not interfere with the hot loop.
-#ifndef MVS_U1
-#define MVS_U1 1  // views kept in flight per step when a single proposal is evaluated (3 is faster in isolation, 1 in the fused sweep: registers)
-#endif
 #ifndef MVS_OUTLINE
 #define MVS_OUTLINE 0
 #endif
@@ -94,22 +91,9 @@ DEV float wave_sum(float x) {
     x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xf, 0xf, true));  // row_bcast:31
     return rlf(x, 63);
 }
-// the same sum for two / three values at once: the steps are written interleaved so that consecutive DPP
-// instructions are independent (a DPP read of a just-written register costs two idle cycles)
+// (bound_ctrl form of a DPP read: lanes without a source read 0)
 template <int CTRL> DEV float dpp0_f(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
-}
-#define MVS_SUM_STEP3(F, C) { const float ta = F<C>(a), tb = F<C>(b), tc = F<C>(c); a = a + ta; b = b + tb; c = c + tc; }
-#define MVS_SUM_STEP2(F, C) { const float ta = F<C>(a), tb = F<C>(b); a = a + ta; b = b + tb; }
-DEV void wave_sum3(float& a, float& b, float& c) {
-    MVS_SUM_STEP3(dpp_f, 0xB1) MVS_SUM_STEP3(dpp_f, 0x4E) MVS_SUM_STEP3(dpp_f, 0x141) MVS_SUM_STEP3(dpp_f, 0x140)
-    MVS_SUM_STEP3(dpp0_f, 0x142) MVS_SUM_STEP3(dpp0_f, 0x143)
-    a = rlf(a, 63); b = rlf(b, 63); c = rlf(c, 63);
-}
-DEV void wave_sum2(float& a, float& b) {
-    MVS_SUM_STEP2(dpp_f, 0xB1) MVS_SUM_STEP2(dpp_f, 0x4E) MVS_SUM_STEP2(dpp_f, 0x141) MVS_SUM_STEP2(dpp_f, 0x140)
-    MVS_SUM_STEP2(dpp0_f, 0x142) MVS_SUM_STEP2(dpp0_f, 0x143)
-    a = rlf(a, 63); b = rlf(b, 63);
 }
 DEV float wave_min(float x) {
     x = fminf(x, dpp_f<0xB1>(x));
