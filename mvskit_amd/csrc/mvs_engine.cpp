@@ -966,7 +966,8 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     mvsk_filter_outside(current_params(e), e->kill.p, st);                       // filterOutside
     HIPCHK(hipEventRecord(e->fev[1], st));
     if (int r = apply_kills(e, &rem[0])) return r;
-    if (int r = filter_rebuild(e, 1)) return r;
+    // a stage that removed nothing leaves the depth maps, hence m_vimages (additive pass) and both grids, as they are
+    if (rem[0] > 0) { if (int r = filter_rebuild(e, 1)) return r; }
     e->fstats.exact_patches = e->fstats.patches_in - rem[0];
     HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
     HIPCHK(hipEventRecord(e->fev[2], st));
@@ -1008,7 +1009,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         HIPCHK(hipEventRecord(e->fev[5], st));
     }
     if (int r = apply_kills(e, &rem[2])) return r;
-    if (int r = filter_rebuild(e, 1)) return r;
+    if (rem[2] > 0) { if (int r = filter_rebuild(e, 1)) return r; }
     {                                                                              // filterSmallGroups
         int64_t alive = 0;
         if (int r = mvs_engine_num_patches(e, &alive)) return r;
@@ -1019,7 +1020,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         HIPCHK(hipEventRecord(e->fev[7], st));
         if (int r = apply_kills(e, &rem[3])) return r;
     }
-    if (int r = filter_rebuild(e, 1)) return r;
+    if (rem[3] > 0) { if (int r = filter_rebuild(e, 1)) return r; }
     if (int r = compact_pool(e)) return r;
     int32_t herr = 0;
     HIPCHK(hipMemcpyAsync(&herr, e->error_flag.p, sizeof herr, hipMemcpyDeviceToHost, st));
