@@ -207,7 +207,11 @@ def main():
                    shard_index=rank, shard_count=world, device=dev_index, nccThreshold=NCC0, depth=DEPTH0)
     if rank == 0:
         log(f"scene ready: {sc.nviews} views {sc.W}x{sc.H}, {seeds.shape[0]} seeds; world {world}" + (" (ranks share a GPU: host-staged exchange over gloo)" if shared_gpu else ""))
-    e.set_scene(sc)
+    torch.cuda.synchronize()
+    t_h0 = time.perf_counter()
+    e.set_scene(sc)  # host images over PCIe + pyramids built on the device (synchronous)
+    torch.cuda.synchronize()
+    host_ms = {"set_views_ms": 1000.0 * (time.perf_counter() - t_h0)}
     exchange = "none"
     ex = None
     if world > 1 or args.force_exchange:
@@ -221,7 +225,10 @@ def main():
     def reset_state():
         """PmMvps::init thresholds + DepthNormInit::createPatches (pmmvps.cpp:54-67,83-85): outside the timed region."""
         e.clear_patches()
+        t_u0 = time.perf_counter()
         e.upload_patches(seeds)
+        torch.cuda.synchronize()
+        host_ms["upload_patches_ms"] = 1000.0 * (time.perf_counter() - t_u0)
         e.set_thresholds(NCC0, NCC_BEFORE0, DEPTH0)
 
     def step(it):
@@ -281,6 +288,11 @@ def main():
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt = float(mx[0]); patches = int(sm[1]); view_evals = int(sm[2])
     n_alive = e.num_patches()
+    t_d0 = time.perf_counter()
+    final_pool = e.patches()  # what a caller takes back over PCIe after the last iteration
+    host_ms["download_patches_ms"] = 1000.0 * (time.perf_counter() - t_d0)
+    host_ms["downloaded_patches"] = int(final_pool.shape[0])
+    del final_pool
 
     if rank == 0:
         reps, extra = divmod(args.steps, SCHEDULE_ITERS)
@@ -352,6 +364,14 @@ def main():
                 "note": "per stage: HIP-event time of its kernel(s) summed over the timed steps; bytes = record (128 B) + per surviving view 5 depth-map cells "
                         "(8 B) with the patch each names (16 B) + 588 B of setRefImage samples + 72 B of lists written (filterExact); record + 8 B per "
                         "list opened + 4 B per id walked + 48 B per distinct patch met + 32 B per neighbour fitted (filterNeighbor)"}
+        if world == 1 and reps >= 1:
+            # what a caller that hands over host buffers sees for ONE 3-iteration job: images and seeds in over PCIe (pyramids built on
+            # the device), the three iterations, the patches back out.  Never `value` (inputs resident), reported beside it.
+            per_job = dt / reps if extra == 0 else dt * SCHEDULE_ITERS / max(args.steps, 1)
+            host_s = 1e-3 * (host_ms["set_views_ms"] + host_ms.get("upload_patches_ms", 0.0) + host_ms["download_patches_ms"])
+            out["host_transfers"] = dict(host_ms, patches_per_job=patches / max(args.steps, 1) * SCHEDULE_ITERS,
+                                         pcie_inclusive_value=(patches / max(args.steps, 1) * SCHEDULE_ITERS) / (per_job + host_s), unit="patches/s",
+                                         note="one job = set_views (host RGB in, pyramids on the device) + upload_patches + 3 iterations + download of the pool")
         if world == 1 and args.cpu_seconds > 0:
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(args, sc, seeds, pool_after_iter0, patches_by_iter if patches_by_iter[0] else [1, 0, 0])
