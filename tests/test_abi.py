@@ -73,3 +73,19 @@ def test_struct_sizes_of_the_binding():
     # mvs_timing: 3 floats, int32, float, (pad), int64; mvs_filter_stats: 6 floats + 8 int64
     assert C.sizeof(engine.Timing) == 32
     assert C.sizeof(engine.FilterStats) == 24 + 8 * 8
+
+
+def test_loopback_transport_exports_what_the_engine_binds():
+    """tests/loopback_ccl (the shared-memory stand-in for RCCL that lets several engine ranks share the one GPU of a test box)
+    must export exactly the eight entry points mvs_engine.cpp binds through MVS_CCL_LIBRARY."""
+    import subprocess
+
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loopback_ccl")
+    subprocess.check_call(["make", "-C", d, "-s"])
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(d, "_build", "libloopback_ccl.so")], text=True)
+    have = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    want = {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclBroadcast", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"}
+    assert want <= have
+    src = open(os.path.join(os.path.dirname(d), "..", "mvskit_amd", "csrc", "mvs_engine.cpp")).read()
+    for name in want:
+        assert f'"{name}"' in src, name

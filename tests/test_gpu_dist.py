@@ -152,3 +152,67 @@ def test_c_abi_exchange_ranks_equal_one_rank(tmp_path, world):
     for f in ("coord", "normal", "ncc", "dscale", "nimages", "images", "nvimages", "vimages"):
         for p in pools:
             np.testing.assert_array_equal(p[f], single[f], err_msg=f)
+
+
+def _worker_host_mirror(rank, world, out_dir):
+    """One rank of the C++ host mirror: PmMvps::setRanks(rank, world, id file) -> init -> run (Propagate::run + Filter::run per
+    iteration), the engine exchanging inside Propagate::run; the collective library is the loopback (ranks share the GPU)."""
+    import ctypes as C
+
+    sys.path.insert(0, ROOT)
+    os.environ["MVS_CCL_LIBRARY"] = LOOPBACK_LIB
+    from mvskit_amd import build, engine
+
+    engine.load_library()
+    L = C.CDLL(build.build_host())
+    L.mvshost_set_ranks.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.mvshost_set_ranks.restype = None
+    L.mvshost_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint,
+                              C.c_int, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
+    sc, seeds = _scene()
+    P = np.ascontiguousarray(sc.P, dtype=np.float32)
+    img = np.ascontiguousarray(sc.images)
+    sd = np.ascontiguousarray(seeds)
+    cap = 400000
+    out = np.zeros(cap, dtype=engine.PATCH_DTYPE)
+    n, ptot = C.c_longlong(), C.c_longlong()
+    L.mvshost_set_ranks(rank, world, os.path.join(out_dir, "comm.id").encode(), 0)
+    r = L.mvshost_run(sc.nviews, sc.W, sc.H, P.ctypes.data, img.ctypes.data, 0, 2, 7, 3, C.c_float(0.7), 5, ITERS, sd.shape[0], sd.ctypes.data,
+                      cap, out.ctypes.data, C.byref(n), C.byref(ptot))
+    assert r == 0, r
+    np.save(os.path.join(out_dir, f"hm_pool_{rank}.npy"), out[: n.value].view(np.uint8))
+    np.save(os.path.join(out_dir, f"hm_total_{rank}.npy"), np.array([ptot.value]))
+
+
+def test_host_mirror_two_ranks_equal_one_rank(tmp_path):
+    """PmMvps::setRanks with world = 2 (mvskit_amd/host): rank 0 writes the communicator id file, rank 1 waits for it, both run
+    the reference's driver sequence; every rank must return the patches of the plain one-rank PmMvps::run."""
+    import ctypes as C
+    import subprocess
+
+    from mvskit_amd import build, engine
+
+    subprocess.check_call(["make", "-C", LOOPBACK_DIR, "-s"])
+    build.build_host()
+    mp.spawn(_worker_host_mirror, args=(2, str(tmp_path)), nprocs=2, join=True)
+    engine.load_library()
+    L = C.CDLL(build.build_host())
+    L.mvshost_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint,
+                              C.c_int, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
+    sc, seeds = _scene()
+    P = np.ascontiguousarray(sc.P, dtype=np.float32)
+    img = np.ascontiguousarray(sc.images)
+    sd = np.ascontiguousarray(seeds)
+    cap = 400000
+    out = np.zeros(cap, dtype=engine.PATCH_DTYPE)
+    n, ptot = C.c_longlong(), C.c_longlong()
+    assert L.mvshost_run(sc.nviews, sc.W, sc.H, P.ctypes.data, img.ctypes.data, 0, 2, 7, 3, C.c_float(0.7), 5, ITERS, sd.shape[0], sd.ctypes.data,
+                         cap, out.ctypes.data, C.byref(n), C.byref(ptot)) == 0
+    single = out[: n.value]
+    assert n.value > seeds.shape[0]
+    for r in range(2):
+        pool = np.load(tmp_path / f"hm_pool_{r}.npy").view(engine.PATCH_DTYPE).reshape(-1)
+        assert pool.shape == single.shape
+        assert pool.tobytes() == single.tobytes()
+    # Propagate::m_pcount is this rank's share: the two shares add up to the one-rank count
+    assert int(sum(np.load(tmp_path / f"hm_total_{r}.npy")[0] for r in range(2))) == ptot.value

@@ -310,6 +310,17 @@ def test_two_view_config(small_plane_scene):
     assert c["patches"] > 300 and c["inserted"] > 100
 
 
+@pytest.mark.parametrize("min_image_num", [5, 8])
+def test_variant_min_image_num(min_image_num):
+    """m_minImageNum 5 and 8 (the engine's limit): tau = 10 and 16 views per cost evaluation -- three and four passes of the
+    single evaluations, ten and sixteen frame lanes per proposal in the refinement steps -- on a 16-view scene whose views all
+    see the plane."""
+    sc = synth.make_scene(nviews=16, W=128, H=96, arc_deg=40.0, radius=4.0, kind="plane")
+    seeds = synth.make_seeds(sc, stride=5, seed=23, views=range(0, 16, 3))
+    c = _one_iteration_matches(sc, seeds, minImageNum=min_image_num, seed=8)
+    assert c["patches"] > 200 and c["inserted"] > 50
+
+
 @pytest.mark.parametrize("list_cap", [32, 16])
 def test_variant_48_views(list_cap):
     # BASELINE.json configs[3] has 48 views: more views than a record stores (MVS_MAX_IMAGES 32) or lists keep, so addImages /
