@@ -215,7 +215,11 @@ def main():
     exchange = "none"
     ex = None
     if world > 1 or args.force_exchange:
-        if shared_gpu:
+        if shared_gpu and os.environ.get("MVS_CCL_LIBRARY"):
+            # rehearsal of the N-GPU code path on fewer GPUs: the engine's own exchange, its collective library replaced (tests/loopback_ccl)
+            ex = mdist.EngineExchange(e, device)
+            exchange = "in-engine exchange through MVS_CCL_LIBRARY=" + os.environ["MVS_CCL_LIBRARY"] + " (rehearsal: ranks share one GPU)"
+        elif shared_gpu:
             ex = mdist.HostStagedExchange(e, device, sc.nviews)
             exchange = "host-staged all-gather over gloo (rehearsal: ranks share one GPU)"
         else:
