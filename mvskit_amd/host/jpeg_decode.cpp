@@ -37,7 +37,7 @@ struct Huff {
             valptr[l] = k;
             mincode[l] = code;
             for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
-                if (k >= 256) return false;
+                if (k >= 256 || code >= (1 << l)) return false;  // more codes of this length than the code space holds
                 if (l <= 9) {
                     const int first = code << (9 - l);
                     for (int f = 0; f < (1 << (9 - l)); ++f) { look_n[first + f] = (uint8_t)l; look_v[first + f] = vals[k]; }
@@ -161,6 +161,7 @@ struct Decoder {
         const int nc = u8();
         if (prec != 8) return fail("unsupported JPEG: only 8-bit samples");
         if (W <= 0 || H <= 0) return fail("unsupported JPEG: image size missing from the frame header");
+        if ((long long)W * H > (1ll << 28)) return fail("unsupported JPEG: more than 2^28 pixels");
         if (nc != 1 && nc != 3) return fail("unsupported JPEG: component count is not 1 or 3");
         if (len != 6 + 3 * nc) return fail("corrupt JPEG: frame header length");
         comps.assign(nc, Component());
@@ -329,35 +330,35 @@ struct Decoder {
     }
 
     // ---- reconstruction
-    static inline uint8_t range_limit(int v) {  // libjpeg's post-IDCT table: index (v & 1023), centred on 128
-        const int i = v & 1023;
+    static inline uint8_t range_limit(int64_t v) {  // libjpeg's post-IDCT table: index (v & 1023), centred on 128
+        const int i = (int)(v & 1023);
         return (uint8_t)(i < 128 ? i + 128 : i < 512 ? 255 : i < 896 ? 0 : i - 896);
     }
     static void idct_islow(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) {  // jidctint.c, jpeg_idct_islow
         enum { CB = 13, P1 = 2 };
-        const int32_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137,
+        const int64_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137,
                       F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
-        auto descale = [](int32_t x, int nb) { return (x + (1 << (nb - 1))) >> nb; };
-        int32_t ws[64];
+        auto descale = [](int64_t x, int nb) { return (x + ((int64_t)1 << (nb - 1))) >> nb; };  // JLONG is 64 bits wide on LP64: a corrupt stream cannot overflow it
+        int64_t ws[64];
         for (int c = 0; c < 8; ++c) {
             const int16_t* ip = in + c;
             const uint16_t* qp = q + c;
-            int32_t* wp = ws + c;
+            int64_t* wp = ws + c;
             if (ip[8] == 0 && ip[16] == 0 && ip[24] == 0 && ip[32] == 0 && ip[40] == 0 && ip[48] == 0 && ip[56] == 0) {
-                const int32_t dcv = (int32_t)ip[0] * qp[0] * (1 << P1);
+                const int64_t dcv = (int64_t)ip[0] * qp[0] * (1 << P1);
                 for (int r = 0; r < 8; ++r) wp[8 * r] = dcv;
                 continue;
             }
-            int32_t z2 = ip[16] * qp[16], z3 = ip[48] * qp[48];
-            int32_t z1 = (z2 + z3) * F0541;
-            int32_t tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
-            z2 = ip[0] * qp[0]; z3 = ip[32] * qp[32];
-            int32_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
-            const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-            tmp0 = ip[56] * qp[56]; tmp1 = ip[40] * qp[40]; tmp2 = ip[24] * qp[24]; tmp3 = ip[8] * qp[8];
+            int64_t z2 = (int64_t)ip[16] * qp[16], z3 = (int64_t)ip[48] * qp[48];
+            int64_t z1 = (z2 + z3) * F0541;
+            int64_t tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+            z2 = (int64_t)ip[0] * qp[0]; z3 = (int64_t)ip[32] * qp[32];
+            int64_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
+            const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+            tmp0 = (int64_t)ip[56] * qp[56]; tmp1 = (int64_t)ip[40] * qp[40]; tmp2 = (int64_t)ip[24] * qp[24]; tmp3 = (int64_t)ip[8] * qp[8];
             z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-            int32_t z4 = tmp1 + tmp3;
-            const int32_t z5 = (z3 + z4) * F1175;
+            int64_t z4 = tmp1 + tmp3;
+            const int64_t z5 = (z3 + z4) * F1175;
             tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
             z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
             z3 += z5; z4 += z5;
@@ -368,17 +369,17 @@ struct Decoder {
             wp[24] = descale(tmp13 + tmp0, CB - P1); wp[32] = descale(tmp13 - tmp0, CB - P1);
         }
         for (int r = 0; r < 8; ++r) {
-            const int32_t* wp = ws + 8 * r;
+            const int64_t* wp = ws + 8 * r;
             uint8_t* op = out + (size_t)r * stride;
-            int32_t z2 = wp[2], z3 = wp[6];
-            int32_t z1 = (z2 + z3) * F0541;
-            int32_t tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
-            int32_t tmp0 = (wp[0] + wp[4]) * (1 << CB), tmp1 = (wp[0] - wp[4]) * (1 << CB);
-            const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+            int64_t z2 = wp[2], z3 = wp[6];
+            int64_t z1 = (z2 + z3) * F0541;
+            int64_t tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+            int64_t tmp0 = (wp[0] + wp[4]) * (1 << CB), tmp1 = (wp[0] - wp[4]) * (1 << CB);
+            const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
             tmp0 = wp[7]; tmp1 = wp[5]; tmp2 = wp[3]; tmp3 = wp[1];
             z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-            int32_t z4 = tmp1 + tmp3;
-            const int32_t z5 = (z3 + z4) * F1175;
+            int64_t z4 = tmp1 + tmp3;
+            const int64_t z5 = (z3 + z4) * F1175;
             tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
             z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
             z3 += z5; z4 += z5;

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <sstream>
 
 namespace mvshost {
@@ -50,13 +51,14 @@ bool read_binary(std::istream& is, Type t, bool swap, double& out) {
 bool read_ascii(std::istream& is, Type t, double& out) {
     double v;
     if (!(is >> v)) return false;
+    auto in = [&](double lo, double hi) { return v >= lo && v <= hi; };  // rply.c rejects an ASCII integer outside its type's range
     switch (t) {
-        case I8: out = (int8_t)v; break;
-        case U8: out = (uint8_t)v; break;
-        case I16: out = (int16_t)v; break;
-        case U16: out = (uint16_t)v; break;
-        case I32: out = (int32_t)v; break;
-        case U32: out = (uint32_t)v; break;
+        case I8: if (!in(-128, 127)) return false; out = (int8_t)v; break;
+        case U8: if (!in(0, 255)) return false; out = (uint8_t)v; break;
+        case I16: if (!in(-32768, 32767)) return false; out = (int16_t)v; break;
+        case U16: if (!in(0, 65535)) return false; out = (uint16_t)v; break;
+        case I32: if (!in(-2147483648.0, 2147483647.0)) return false; out = (int32_t)v; break;
+        case U32: if (!in(0, 4294967295.0)) return false; out = (uint32_t)v; break;
         case F32: out = (float)v; break;
         default: out = v; break;
     }
@@ -85,7 +87,7 @@ int readPlyVertices(const std::string& file, std::vector<double>& points, std::v
             format = f == "ascii" ? 0 : f == "binary_little_endian" ? 1 : f == "binary_big_endian" ? 2 : -1;
         } else if (key == "element") {
             Element e;
-            if (!(ls >> e.name >> e.n) || e.n < 0) return fail("bad element line in the PLY header");
+            if (!(ls >> e.name >> e.n) || e.n < 0 || e.n > (1ll << 31)) return fail("bad element line in the PLY header");
             elements.push_back(e);
         } else if (key == "property") {
             if (elements.empty()) return fail("property before any element in the PLY header");
@@ -119,8 +121,10 @@ int readPlyVertices(const std::string& file, std::vector<double>& points, std::v
             static const char* names[6] = {"x", "y", "z", "nx", "ny", "nz"};
             for (int k = 0; k < 6; ++k) for (size_t i = 0; i < e.props.size(); ++i) if (!e.props[i].list && e.props[i].name == names[k]) slot[k] = (int)i;
             if (slot[0] < 0 || slot[1] < 0 || slot[2] < 0) return fail("PLY vertex element without x y z");
-            points.assign((size_t)e.n * 3, 0.0);
-            if (normals && slot[3] >= 0 && slot[4] >= 0 && slot[5] >= 0) normals->assign((size_t)e.n * 3, 0.0);
+            try {
+                points.assign((size_t)e.n * 3, 0.0);
+                if (normals && slot[3] >= 0 && slot[4] >= 0 && slot[5] >= 0) normals->assign((size_t)e.n * 3, 0.0);
+            } catch (const std::bad_alloc&) { return fail("PLY vertex count does not fit in memory"); }
         }
         for (long long i = 0; i < e.n; ++i) {
             for (size_t pi = 0; pi < e.props.size(); ++pi) {
