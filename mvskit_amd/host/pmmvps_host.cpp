@@ -112,7 +112,7 @@ static bool pnm_header(std::istream& is, const char* magic, int& w, int& h, int&
     auto skip = [&]() { while (is >> std::ws && is.peek() == '#') { string l; std::getline(is, l); } };
     skip(); is >> w; skip(); is >> h; skip(); is >> maxv;
     is.get();
-    return (bool)is && w > 0 && h > 0 && maxv == 255;
+    return (bool)is && w > 0 && h > 0 && w <= 65535 && h <= 65535 && maxv == 255;
 }
 int Photo::readPpm(const string iname) {
     ifstream is(iname.c_str(), std::ios::binary);
