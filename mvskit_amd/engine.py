@@ -71,7 +71,7 @@ def load_library(cap32: bool = False):
     """Loads libmvskit_engine.so -- or, for view lists of up to 32 entries, libmvskit_engine_cap32.so (the same sources
     built with -DMVS_LISTCAP=32) -- built in-tree by mvskit_amd.build / __graft_entry__.build."""
     default = build.LIB32_PATH if cap32 else build.LIB_PATH
-    LIB_PATH = default if cap32 else os.environ.get("MVS_ENGINE_LIB", default)  # development: A/B timing of two builds on one box
+    LIB_PATH = os.environ.get("MVS_ENGINE_LIB32" if cap32 else "MVS_ENGINE_LIB", default)  # development: A/B timing of two builds on one box
     if LIB_PATH in _libs:
         return _libs[LIB_PATH]
     if not os.path.exists(LIB_PATH):
