@@ -491,7 +491,7 @@ DEV void eval_steps4(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const 
     }
     {   // the reference view
         const float4 pv = mvs_dyn_lds4[MVS_PIVOT_LDS4];
-        const ClsFrame fn = cls_frame(fb + min(1, n - 1));
+        const ClsFrame fn = cls_frame(fb + min(1, max(n - 1, 0)));
         float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -508,7 +508,7 @@ DEV void eval_steps4(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const 
     }
     for (int k = 1; k < n; ++k) {
         const float4 pv = mvs_dyn_lds4[MVS_PIVOT_LDS4 + k];
-        const ClsFrame fn = cls_frame(fb + min(k + 1, n - 1));
+        const ClsFrame fn = cls_frame(fb + min(k + 1, max(n - 1, 0)));
         float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f, s2 = 0.0f, s01 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -603,16 +603,17 @@ DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsi
     float ssd_l = 1.0f, dot_l = 0.0f, mr_l = 128.0f, mg_l = 128.0f, mb_l = 128.0f;
     ClsPend pend[3];
     {
-        const ClsFrame fr = cls_frame(min(row, n - 1));
+        const int last = max(n - 1, 0);  // an empty list never reaches this point; the clamps below stay inside the frames all the same
+        const ClsFrame fr = cls_frame(min(row, last));
 #pragma unroll
         for (int j = 0; j < 3; ++j) pend[j] = cls_issue(fr, cls_opaque(cc.cs[j]));
     }
     if (cc.nx > 0) cls_raw(pe, xcs, fxr, fxg, fxb);
     const int rounds = (n + 3) >> 2;
     for (int t = 0; t < rounds; ++t) {
-        const int v = 4 * t + row, vq = min(v, n - 1);
+        const int v = 4 * t + row, vq = min(v, max(n - 1, 0));
 #if MVS_EV_PREFETCH
-        const ClsFrame fn = cls_frame(min(v + 4, n - 1));
+        const ClsFrame fn = cls_frame(min(v + 4, max(n - 1, 0)));
 #endif
         float cr[3], cg[3], cb[3];
         float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f;
@@ -659,7 +660,7 @@ DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsi
         if (lc == t) { ssd_l = sq; dot_l = dt; if (PIV) { mr_l = mr; mg_l = mg; mb_l = mb; } }
 #if !MVS_EV_PREFETCH
         if (t + 1 < rounds) {
-            const ClsFrame fn = cls_frame(min(v + 4, n - 1));
+            const ClsFrame fn = cls_frame(min(v + 4, max(n - 1, 0)));
 #pragma unroll
             for (int j = 0; j < 3; ++j) pend[j] = cls_issue(fn, cls_opaque(cc.cs[j]));
         }
