@@ -297,3 +297,170 @@ def test_texture_and_incc_second_reading(setup):
     assert checked > 60
     for r in np.linspace(0, 0.33, 12):
         assert abs(ob.lib().orc_robustincc(float(r)) - ref_robustincc(r)) < 1e-7
+
+
+# ------------------------------------------------------------------ refinement variables, cost, scales, neighbours
+ASCALE = F(np.pi / F(48.0))  # Optim::refinePatch, optim.cpp:487
+
+
+def ref_encode(cam, center, ray, dscale, coord, normal):
+    """Optim::encode, optim.cpp:549-580 (libm calls; the oracle's own polynomials are within 3e-7 of them)."""
+    x0 = F(np.dot((coord - center).astype(F), ray)) / F(dscale)
+    n3 = normal[:3].astype(F)
+    fx, fy, fz = F(np.dot(cam.xaxis, n3)), F(np.dot(cam.yaxis, n3)), F(np.dot(cam.zaxis, n3))
+    a2 = F(np.arcsin(max(F(-1), min(F(1), fy))))
+    cosb = F(np.cos(a2))
+    if cosb == 0:
+        a1 = F(0)
+    else:
+        sina, cosa = F(fx / cosb), F(-fz / cosb)
+        a1 = F(np.arccos(max(F(-1), min(F(1), cosa))))
+        if sina < 0:
+            a1 = -a1
+    return np.array([x0, a1 / ASCALE, a2 / ASCALE], F)
+
+
+def ref_decode(cam, center, ray, dscale, x):
+    """Optim::decode, optim.cpp:582-599."""
+    coord = (center + F(dscale) * F(x[0]) * ray).astype(F)
+    a1, a2 = F(x[1] * ASCALE), F(x[2] * ASCALE)
+    fx, fy, fz = F(np.sin(a1) * np.cos(a2)), F(np.sin(a2)), F(-np.cos(a1) * np.cos(a2))
+    n3 = (cam.xaxis * fx + cam.yaxis * fy + cam.zaxis * fz).astype(F)
+    return coord, np.append(n3, F(0))
+
+
+def ref_cost_func(cams, pyrs, center, ray, dscale, idx, x, level, wsize, tau, min_image_num, cos_thr):
+    """Optim::cost_func, optim.cpp:401-468 (the non-pairwise branch)."""
+    coord, normal = ref_decode(cams[idx[0]], center, ray, dscale, x)
+    px, py = ref_get_paxes(cams[idx[0]], coord, normal, level)
+    sz = min(tau, len(idx))
+    minimum = min(min_image_num, sz)
+    texs = []
+    for i in range(sz):
+        t = ref_get_tex(cams[idx[i]], pyrs[idx[i]], coord, px, py, normal, level, wsize, cos_thr)
+        texs.append(None if t is None else ref_normalize(t))
+    if texs[0] is None:
+        return 2.0
+    ans, denom = 0.0, 0
+    for i in range(1, sz):
+        if texs[i] is None:
+            continue
+        ans += float(ref_robustincc(F(1.0 - float(ref_dot(texs[0], texs[i])))))
+        denom += 1
+    return 2.0 if denom < minimum - 1 else ans / denom
+
+
+def ref_set_scales(cams, coord, idx, level, wsize, tau):
+    """PatchManager::setScales, patch_manager.cpp:378-399 (m_dscale starts at 0, patch.cpp:13-25)."""
+    unit = ref_get_unit(cams[idx[0]], coord, level)
+    unit2 = F(2) * unit
+    ray = (coord - cams[idx[0]].center).astype(F)
+    ray = (ray / np.linalg.norm(ray).astype(F)).astype(F)
+    num = min(tau, len(idx))
+    ds = F(0)
+    for i in range(1, num):
+        P = cams[idx[i]].P[level]
+        diff = (ref_project(P, coord) - ref_project(P, (coord - unit2 * ray).astype(F))).astype(F)
+        ds = F(ds + np.linalg.norm(diff).astype(F))
+    ds = F(ds / F(num - 1))
+    ds = F(unit2 / ds)
+    return ds, F(np.arctan(ds / (unit * F(wsize) / F(2))))
+
+
+def ref_is_neighbor(cams, a, b, csize, level, thr):
+    """PmMvps::isNeighbor, pmmvps.cpp:117-147 -- including the reference's constant cosf(120 / pi * 180)."""
+    hunit = F((ref_get_unit(cams[int(a["images"][0])], a["coord"].astype(F), level) + ref_get_unit(cams[int(b["images"][0])], b["coord"].astype(F), level)) / F(2) * F(csize))
+    na, nb = a["normal"].astype(F), b["normal"].astype(F)
+    if F(np.dot(na, nb)) < F(np.cos(F(F(120.0) / F(np.pi) * F(180.0)))):
+        return 0
+    diff = (a["coord"] - b["coord"]).astype(F)
+    vunit = F(a["dscale"] + b["dscale"])
+    f0, f1 = F(np.dot(na, diff)), F(np.dot(nb, diff))
+    ftmp = F(F(abs(f0) + abs(f1)) / F(2) / vunit)
+    hsize = F(np.linalg.norm((diff - f0 * na + diff - f1 * nb).astype(F)).astype(F) / F(2) / hunit)
+    if 1.0 < hsize:
+        ftmp = F(ftmp / min(F(2), hsize))
+    return 1 if ftmp < thr else 0
+
+
+def test_encode_decode_and_cost_second_reading(setup):
+    sc, o, cams, pyrs, seeds = setup
+    cos_thr = F(np.cos(F(60.0 * np.pi / 180.0)))
+    rng = np.random.RandomState(7)
+    checked = 0
+    for s in seeds[:40]:
+        idx = [int(i) for i in s["images"][: s["nimages"]]]
+        if len(idx) < 2:
+            continue
+        X, N = s["coord"].astype(F), s["normal"].astype(F)
+        rec = s.copy()
+        rec["dscale"] = F(0.01)
+        cam = cams[idx[0]]
+        ray = (X - cam.center).astype(F)
+        ray = (ray / np.linalg.norm(ray).astype(F)).astype(F)
+        x = ref_encode(cam, X, ray, rec["dscale"], X, N)
+        np.testing.assert_allclose(o.encode(rec), x, rtol=0, atol=2e-4)  # angles in units of pi/48: 2e-4 units = 1.3e-5 rad
+        x2 = (x + rng.uniform(-1.5, 1.5, 3)).astype(F)
+        c, n = o.decode(rec, x2)
+        rc, rn = ref_decode(cam, X, ray, rec["dscale"], x2)
+        np.testing.assert_allclose(c, rc, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(n, rn, rtol=0, atol=2e-6)
+        got = o.cost(rec, x2)
+        exp = ref_cost_func(cams, pyrs, X, ray, rec["dscale"], idx, x2, 0, 7, min(4, sc.nviews), 2, cos_thr)
+        assert abs(got - exp) <= 5e-5 * max(1.0, abs(exp)), (got, exp)
+        checked += 1
+    assert checked > 25
+
+
+def test_scales_and_neighbours_second_reading(setup):
+    sc, o, cams, pyrs, seeds = setup
+    tau = min(4, sc.nviews)
+    done = []
+    for s in seeds[:60]:
+        f, rec = o.preprocess(s)
+        if f != 0:
+            continue
+        idx = [int(i) for i in rec["images"][: rec["nimages"]]]
+        ds, asc = ref_set_scales(cams, rec["coord"].astype(F), idx, 0, 7, tau)
+        # m_dscale is a quotient of ~1-pixel differences of projections ~100 pixels large: rounding of the projections (fused or not)
+        # shows at 1e-5 relative
+        assert abs(rec["dscale"] - ds) <= 2e-4 * ds and abs(rec["ascale"] - asc) <= 2e-4 * asc, (rec["dscale"], ds, rec["ascale"], asc)
+        done.append(rec)
+    assert len(done) > 30
+    pairs = same = 0
+    for i in range(0, len(done) - 1):
+        for j in (i + 1, (i + 7) % len(done)):
+            if i == j:
+                continue
+            for thr in (0.25, 1.0, 4.0):
+                pairs += 1
+                same += o.is_neighbor(done[i], done[j], thr) == ref_is_neighbor(cams, done[i], done[j], 2, 0, thr)
+    assert pairs > 100 and same == pairs
+
+
+def test_generate_patch_second_reading(setup):
+    """Propagate::generatePatch, propagate.cpp:220-237: depth along the optical axis of the source's reference view, the pixel
+    unprojected at that depth, the source's normal; views whose cell falls outside the grid are dropped (setGridsImages)."""
+    sc, o, cams, pyrs, seeds = setup
+    rng = np.random.RandomState(11)
+    checked = 0
+    for s in seeds[:60]:
+        v = int(s["images"][0])
+        X = s["coord"].astype(F)
+        ic0 = ref_project(cams[v].P[0], X)
+        ic = np.array([ic0[0] + rng.uniform(-3, 3), ic0[1] + rng.uniform(-3, 3), 1.0], F)
+        f, rec = o.generate_patch(s, ic)
+        if f != 0:
+            continue
+        depth = F(np.dot(cams[v].oaxis, X))
+        exp = ref_unproject(cams[v].P[0], (depth * ic).astype(F))
+        np.testing.assert_allclose(rec["coord"], exp, rtol=2e-5, atol=2e-5)
+        np.testing.assert_array_equal(rec["normal"], s["normal"])
+        kept = [int(i) for i in rec["images"][: rec["nimages"]]]
+        assert kept and kept[0] == v and set(kept) <= {int(i) for i in s["images"][: s["nimages"]]}
+        for i in kept:  # every kept view sees the new point inside its grid (cells of csize 2 at level 0)
+            p = ref_project(cams[i].P[0], exp)
+            gx, gy = int(np.floor(p[0] + F(0.5))) // 2, int(np.floor(p[1] + F(0.5))) // 2
+            assert 0 <= gx < (sc.W + 1) // 2 and 0 <= gy < (sc.H + 1) // 2
+        checked += 1
+    assert checked > 40
