@@ -1291,19 +1291,19 @@ bool solve5(double M[5][6], double* x) {
     return true;
 }
 
-/* Filter::filterQuad, filter.cpp:329-392 */
-int filter_quad(const Scene& s, const Patch& p, const std::vector<int>& nb, const DestCtx* ctx) {
+/* Filter::filterQuad, filter.cpp:329-392: the residual of the quadric fitted to the neighbours' coordinates */
+float quad_residual(const Scene& s, const Patch& p, const std::vector<V4>& nc) {
     V4 xdir, ydir;
     ortho(p.normal, xdir, ydir);
-    const int n = (int)nb.size();
+    const int n = (int)nc.size();
     std::vector<float> dist(n);
-    for (int i = 0; i < n; ++i) dist[i] = norm4(sub4(get_patch(s, nb[i], ctx).coord, p.coord));
+    for (int i = 0; i < n; ++i) dist[i] = norm4(sub4(nc[i], p.coord));
     float h = reduce_n_f32(s, dist);
     h /= n;
     std::vector<std::array<float, 5>> A(n);
     std::vector<float> b(n), fxs(n), fys(n), fzs(n);
     for (int i = 0; i < n; ++i) {
-        const V4 diff = sub4(get_patch(s, nb[i], ctx).coord, p.coord);
+        const V4 diff = sub4(nc[i], p.coord);
         fxs[i] = dot4(diff, xdir) / h;
         fys[i] = dot4(diff, ydir) / h;
         fzs[i] = dot4(diff, p.normal);
@@ -1327,7 +1327,12 @@ int filter_quad(const Scene& s, const Patch& p, const std::vector<int>& nb, cons
     }
     float residual = reduce_n_f32(s, rs);
     residual /= (n - 5);
-    return residual < s.cfg.quadThreshold ? 0 : 1;
+    return residual;
+}
+int filter_quad(const Scene& s, const Patch& p, const std::vector<int>& nb, const DestCtx* ctx) {
+    std::vector<V4> nc(nb.size());
+    for (size_t i = 0; i < nb.size(); ++i) nc[i] = get_patch(s, nb[i], ctx).coord;
+    return quad_residual(s, p, nc) < s.cfg.quadThreshold ? 0 : 1;
 }
 
 /* Optim::check, optim.cpp:300-323 */
@@ -2311,6 +2316,12 @@ int orc_generate_patch(orc_scene* h, const orc_patch* src, const float* ic, orc_
     Patch p, q; prep_probe(h->s, src, p);
     if (!generate_patch(h->s, p, {ic[0], ic[1], ic[2]}, q, nullptr)) return -1;
     to_rec(q, -1, *out); return 0;
+}
+float orc_quad_residual(orc_scene* h, const orc_patch* r, const float* coords4, int n) {
+    Patch p; prep_probe(h->s, r, p);
+    std::vector<V4> nc((size_t)n);
+    for (int i = 0; i < n; ++i) nc[(size_t)i] = {coords4[4 * i], coords4[4 * i + 1], coords4[4 * i + 2], coords4[4 * i + 3]};
+    return quad_residual(h->s, p, nc);
 }
 float orc_robustincc(float v) { return robustincc(v); }
 float orc_unrobustincc(float v) { return unrobustincc(v); }

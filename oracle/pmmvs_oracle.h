@@ -153,6 +153,7 @@ double orc_cost(orc_scene* s, const orc_patch* p, const float* x3);             
 int orc_encode(orc_scene* s, const orc_patch* p, float* x3);                                     /* optim.cpp:549-580 */
 int orc_decode(orc_scene* s, const orc_patch* p, const float* x3, float* coord4, float* normal4);/* optim.cpp:582-599 */
 int orc_generate_patch(orc_scene* s, const orc_patch* src, const float* icoord3, orc_patch* out);/* propagate.cpp:220-237 */
+float orc_quad_residual(orc_scene* s, const orc_patch* p, const float* coords4, int n);            /* filter.cpp:329-392: the residual filterQuad compares with m_quadThreshold */
 float orc_robustincc(float incc);
 float orc_unrobustincc(float rincc);
 void orc_minstd_draws(int n, float* out);  /* propagate.cpp:139-140 on this libstdc++ */

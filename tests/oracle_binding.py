@@ -111,6 +111,8 @@ def lib():
     L.orc_encode.argtypes = [vp, vp, vp]
     L.orc_decode.argtypes = [vp, vp, vp, vp, vp]
     L.orc_generate_patch.argtypes = [vp, vp, vp, vp]
+    L.orc_quad_residual.argtypes = [vp, vp, vp, C.c_int]
+    L.orc_quad_residual.restype = C.c_float
     L.orc_robustincc.argtypes = [C.c_float]
     L.orc_robustincc.restype = C.c_float
     L.orc_unrobustincc.argtypes = [C.c_float]
@@ -376,6 +378,10 @@ class Oracle:
 
     def is_neighbor(self, a, b, thr):
         return self.L.orc_is_neighbor(self.h, _ptr(self._one(a)), _ptr(self._one(b)), thr)
+
+    def quad_residual(self, rec, coords):
+        c = np.ascontiguousarray(coords, dtype=np.float32)
+        return self.L.orc_quad_residual(self.h, _ptr(self._one(rec)), _ptr(c), c.shape[0])
 
     def compute_gain(self, rec):
         return self.L.orc_compute_gain(self.h, _ptr(self._one(rec)))

@@ -464,3 +464,62 @@ def test_generate_patch_second_reading(setup):
             assert 0 <= gx < (sc.W + 1) // 2 and 0 <= gy < (sc.H + 1) // 2
         checked += 1
     assert checked > 40
+
+
+def ref_quad_residual(cams, rec, coords, level, tau):
+    """Filter::filterQuad / ortho / lls, filter.cpp:329-430: the least-squares quadric through the neighbours by SVD
+    (Eigen's jacobiSvd().solve there, numpy's lstsq here), in float like the reference."""
+    z = rec["normal"].astype(F)
+    if abs(z[0]) > 0.5:
+        x = np.array([z[1], -z[0], 0, 0], F)
+    elif abs(z[1]) > 0.5:
+        x = np.array([0, z[2], -z[1], 0], F)
+    else:
+        x = np.array([-z[2], 0, z[0], 0], F)
+    x = (x / np.linalg.norm(x).astype(F)).astype(F)
+    y = np.array([z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0], 0], F)
+    diff = (coords.astype(F) - rec["coord"].astype(F)).astype(F)
+    h = F(0)
+    for d in diff:
+        h = F(h + np.linalg.norm(d).astype(F))
+    h = F(h / F(len(diff)))
+    fx, fy, fz = (diff @ x / h).astype(F), (diff @ y / h).astype(F), (diff @ z).astype(F)
+    A = np.stack([fx * fx, fy * fy, fx * fy, fx, fy], 1).astype(F)
+    sol = np.linalg.lstsq(A, fz, rcond=None)[0].astype(F)
+    idx = [int(i) for i in rec["images"][: rec["nimages"]]]
+    inum = min(tau, len(idx))
+    unit = F(0)
+    for i in range(inum):
+        unit = F(unit + ref_get_unit(cams[idx[i]], rec["coord"].astype(F), level))
+    unit = F(unit / F(inum))
+    res = F(0)
+    for n in range(len(diff)):
+        r = sol[0] * (fx[n] * fx[n]) + sol[1] * (fy[n] * fy[n]) + sol[2] * (fx[n] * fy[n]) + sol[3] * fx[n] + sol[4] * fy[n] - fz[n]
+        res = F(res + F(abs(r)) / unit)
+    return F(res / F(len(diff) - 5))
+
+
+def test_filter_quad_second_reading(setup):
+    """The oracle solves the 5-parameter fit by normal equations in double, the reference by an SVD in float: the residual the
+    decision rests on must agree (a curved, noisy neighbourhood and a flat one; the decision threshold is 2.5)."""
+    sc, o, cams, pyrs, seeds = setup
+    rng = np.random.RandomState(13)
+    worst = 0.0
+    for k, s in enumerate(seeds[:40]):
+        n = int(rng.randint(7, 120))
+        unit = float(ref_get_unit(cams[int(s["images"][0])], s["coord"].astype(F), 0))
+        z = s["normal"][:3].astype(np.float64)
+        t1 = np.cross(z, [1.0, 0.3, 0.2]); t1 /= np.linalg.norm(t1)
+        t2 = np.cross(z, t1)
+        uv = rng.uniform(-6, 6, (n, 2)) * unit
+        curv = (0.0 if k % 3 == 0 else rng.uniform(-0.5, 0.5)) / unit
+        noise = rng.normal(0, (0.1, 1.0, 4.0)[k % 3] * unit, n)
+        hgt = curv * (uv[:, 0] ** 2 - 0.5 * uv[:, 1] ** 2 + 0.3 * uv[:, 0] * uv[:, 1]) + 0.2 * uv[:, 0] + noise
+        pts = s["coord"][:3].astype(np.float64) + uv[:, :1] * t1 + uv[:, 1:] * t2 + hgt[:, None] * z
+        coords = np.concatenate([pts, np.ones((n, 1))], 1).astype(F)
+        got = float(o.quad_residual(s, coords))
+        exp = float(ref_quad_residual(cams, s, coords, 0, min(4, sc.nviews)))
+        assert abs(got - exp) <= 2e-3 * max(exp, 1e-3), (k, n, got, exp)
+        assert (got < 2.5) == (exp < 2.5)
+        worst = max(worst, abs(got - exp) / max(exp, 1e-3))
+    assert worst < 2e-3
