@@ -16,6 +16,12 @@ echo "== bench --filter"; timeout -k 10 500 $B --filter --cpu-seconds 0 > $out/$
 echo "== kernel trace --filter"; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktf -o ktf -- $B --filter --cpu-seconds 0 > $out/ktf.log 2>&1
 echo "== pmc fetch --filter"; timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetchf -o fetchf -- $B --filter --cpu-seconds 0 > $out/fetchf.log 2>&1
 echo "== pmc write --filter"; timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/writef -o writef -- $B --filter --cpu-seconds 0 > $out/writef.log 2>&1
+echo "== instruction mix (four passes)"
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 --output-format csv -d $out/mixa -o a -- $B --cpu-seconds 0 > $out/mixa.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $out/mixb -o b -- $B --cpu-seconds 0 > $out/mixb.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_SALU --output-format csv -d $out/mixc -o c -- $B --cpu-seconds 0 > $out/mixc.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT --output-format csv -d $out/mixd -o d -- $B --cpu-seconds 0 > $out/mixd.log 2>&1
 cd $GRAFT_REPO_ROOT
+python3 tools/pmc_mix.py $(find $out/mixa $out/mixb $out/mixc $out/mixd -name "*counter_collection.csv") > $out/${R}_pmc_mix_k_sweep.json
 python3 tools/pmc_sq.py $(find $out/sq -name "*counter_collection.csv" | head -1) > $out/${R}_pmc_sq_k_sweep.json
 find $out -name "*.csv" | head -30
