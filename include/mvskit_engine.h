@@ -177,7 +177,10 @@ int mvs_engine_commit_local(mvs_engine* e);
  * final place behind the pool (ranges are contiguous, so rank order IS the global (view, cell, creation) order), and
  * (3) the ids of evicted patches -- then commits the union, so all pools stay identical and equal to the 1-GPU result.
  * With a communicator attached, mvs_engine_propagate does pass + exchange itself: PmMvps::run needs no other change.
- * librccl is opened at run time (dlopen); without it these calls return MVS_ERR_STATE and everything else still works. */
+ * librccl is opened at run time (dlopen); without it these calls return MVS_ERR_STATE and everything else still works.
+ * Environment: MVS_CCL_LIBRARY=<path> opens that library instead -- anything exporting ncclGetUniqueId, ncclCommInitRank,
+ * ncclCommDestroy, ncclAllGather, ncclBroadcast, ncclGroupStart, ncclGroupEnd, ncclGetErrorString (a site's own RCCL build; the
+ * shared-memory loopback of tests/loopback_ccl, with which several ranks can share the one GPU of a test box). */
 #define MVS_COMM_ID_BYTES 128
 int mvs_comm_unique_id(void* id_out /* MVS_COMM_ID_BYTES */); /* ncclGetUniqueId: rank 0 calls it and hands the bytes to the other ranks (file, socket, MPI ...) */
 int mvs_engine_comm_init(mvs_engine* e, const void* id /* MVS_COMM_ID_BYTES */, int rank, int world); /* ncclCommInitRank on the engine's device; collective */
