@@ -2,9 +2,9 @@
 //
 // Execution model: ONE 64-lane wavefront works on one patch / one destination cell.  Control flow is
 // wave-uniform.  Three lane layouts coexist in registers:
-//   * sample lanes: lane i < wsize*wsize holds sample i of the 7x7 texture window (optim.cpp:835-842);
-//     channel sums, the ssd and the NCC dot product are wave butterflies (DPP + v_readlane), pairing order
-//     1,2,4,8,16,32;
+//   * class lanes: lane 16 r + c holds samples c, c + 16, c + 32 of the 7x7 texture window (optim.cpp:835-842) its 16-lane
+//     row works on -- a proposal in a refinement step, a view in a single evaluation; sums over a window are lane sums, a
+//     DPP row tree (pairing 1, 2, 4, 8) and the window's 49th sample, taken by the lane that owns the sampling frame;
 //   * view lanes: lane j holds element j of a per-view array (Patch::m_images[j], its ray, unit, INCC ...),
 //     read back with v_readlane when a loop needs element j uniformly;
 //   * frame lanes: lane 16*g + i holds the sampling frame of view i for proposal g (g < 4): the four
@@ -394,7 +394,7 @@ DEV float inv_msd(const DParams& prm, float ssd) {
 // running sums -- colour, colour^2 and colour x reference colour (the reference view's colours of its own samples stay in
 // registers) -- so no sum crosses lanes per sample.  Per view the five sums are finished by the four DPP steps of a
 // 16-lane row, once for all four proposals, and dropped into view lane 16 g + k; the per-view scalars (1/msd, INCC) then
-// come out of one vector sequence as in eval_core.  A wave instruction of the view loop covers 64 samples.
+// come out of one vector sequence.  A wave instruction of the view loop covers 64 samples.
 // The few samples beyond the last full 16 ("extras": sample 48 of a 7x7 window) are taken afterwards by the FRAME lanes:
 // lane 16 g + k samples them in its own frame (proposal g, view k) and adds them to the sums it has just received.
 // Arithmetic (mirrored by the oracle, tex_stats_class16): colours are taken relative to a per-view pivot p (the view's
