@@ -358,18 +358,23 @@ DEV double shfl_f64(double x, int src) {
 DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, const int* nb, int n, float* rows) {
     F4 xdir, ydir;
     ortho(c.normal, xdir, ydir);
+    // one pass over the neighbours' records: the distance for the mean h, and the three projections of the offset, which wait
+    // in the rows for the division by h
     float hp = 0.0f;
-    for (int t = wc.lane; t < n; t += 64) hp += norm4(sub4(ld4(patch_ptr(prm, cx, nb[t])->coord), c.coord));
+    for (int t = wc.lane; t < n; t += 64) {
+        const F4 diff = sub4(ld4(patch_ptr(prm, cx, nb[t])->coord), c.coord);
+        hp += norm4(diff);
+        rows[3 * t + 0] = dot4(diff, xdir); rows[3 * t + 1] = dot4(diff, ydir); rows[3 * t + 2] = dot4(diff, c.normal);
+    }
     float h = wave_sum(hp);
     h /= (float)n;
     // Filter::lls: M = [A^T A | A^T b] with A = (fx^2, fy^2, fx fy, fx, fy), b = fz; 15 + 5 distinct sums, in double
     double acc[20];
 #pragma unroll
     for (int k = 0; k < 20; ++k) acc[k] = 0.0;
-    for (int t = wc.lane; t < n; t += 64) {
-        const F4 diff = sub4(ld4(patch_ptr(prm, cx, nb[t])->coord), c.coord);
-        const float fx = dot4(diff, xdir) / h, fy = dot4(diff, ydir) / h, fz = dot4(diff, c.normal);
-        rows[3 * t + 0] = fx; rows[3 * t + 1] = fy; rows[3 * t + 2] = fz;
+    for (int t = wc.lane; t < n; t += 64) {  // each lane reads back what it wrote
+        const float fx = rows[3 * t + 0] / h, fy = rows[3 * t + 1] / h, fz = rows[3 * t + 2];
+        rows[3 * t + 0] = fx; rows[3 * t + 1] = fy;
         const float a[6] = {fx * fx, fy * fy, fx * fy, fx, fy, fz};
         int k = 0;
 #pragma unroll
