@@ -523,3 +523,32 @@ def test_filter_quad_second_reading(setup):
         assert (got < 2.5) == (exp < 2.5)
         worst = max(worst, abs(got - exp) / max(exp, 1e-3))
     assert worst < 2e-3
+
+
+def test_set_inccs_matrix_second_reading(setup):
+    """Optim::setINCCs (matrix form, optim.cpp:748-783), what Optim::setRefImage (348-383) sums by rows to pick the reference view."""
+    sc, o, cams, pyrs, seeds = setup
+    cos_thr = F(np.cos(F(60.0 * np.pi / 180.0)))
+    checked = 0
+    for s in seeds[:40]:
+        idx = [int(i) for i in s["images"][: s["nimages"]]]
+        if len(idx) < 3:
+            continue
+        X, N = s["coord"].astype(F), s["normal"].astype(F)
+        px, py = ref_get_paxes(cams[idx[0]], X, N, 0)
+        texs = []
+        for v in idx:
+            t = ref_get_tex(cams[v], pyrs[v], X, px, py, N, 0, 7, cos_thr)
+            texs.append(None if t is None else ref_normalize(t))
+        n = len(idx)
+        exp = np.zeros((n, n), F)
+        for i in range(n):
+            for j in range(i + 1, n):
+                exp[i, j] = exp[j, i] = F(2) if texs[i] is None or texs[j] is None else ref_robustincc(F(1) - ref_dot(texs[i], texs[j]))
+        got = o.set_inccs_matrix(s, robust=1)
+        np.testing.assert_allclose(got, exp, rtol=0, atol=5e-5)
+        sums_e, sums_g = exp.sum(1), got.sum(1)
+        if np.sort(sums_e)[1] - np.sort(sums_e)[0] > 1e-3:  # away from ties both readings choose the same reference view
+            assert int(np.argmin(sums_e)) == int(np.argmin(sums_g))
+        checked += 1
+    assert checked > 15
