@@ -339,11 +339,14 @@ int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
     return MVS_OK;
 }
 // Filter::setDepthMapsVGridsVPGridsAddPatchV, filter.cpp:628-655
-int filter_rebuild(mvs_engine* e, int additive) {
-    if (int r = build_list(e, false, false)) return r;
+// setDepthMapsVGridsVPGridsAddPatchV between the stages of Filter::run.  The depth maps and m_vimages come from the pool; the two
+// grid indexes are built only for a stage that walks them: filterOutside (computeGain) reads m_pgrids, filterExact neither,
+// filterNeighbor and filterSmallGroups both -- and after the last stage the pool is compacted, which invalidates them anyway.
+int filter_rebuild(mvs_engine* e, int additive, bool need_pgrid, bool need_vpgrid) {
+    if (need_pgrid) { if (int r = build_list(e, false, false)) return r; }
     if (int r = build_depth(e)) return r;
     mvsk_filter_vimages(current_params(e), additive, e->stream);
-    if (int r = build_list(e, true, false)) return r;
+    if (need_vpgrid) { if (int r = build_list(e, true, false)) return r; }
     HIPCHK(hipGetLastError());
     return MVS_OK;
 }
@@ -961,13 +964,13 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     if (int r = e->fstat_buf.ensure(4096)) return r;
     HIPCHK(hipMemsetAsync(e->fstat_buf.p, 0, 4096 * sizeof(unsigned long long), st));
     if (int r = mvs_engine_num_patches(e, &e->fstats.patches_in)) return r;
-    if (int r = filter_rebuild(e, 0)) return r;
+    if (int r = filter_rebuild(e, 0, true, false)) return r;
     HIPCHK(hipEventRecord(e->fev[0], st));
     mvsk_filter_outside(current_params(e), e->kill.p, st);                       // filterOutside
     HIPCHK(hipEventRecord(e->fev[1], st));
     if (int r = apply_kills(e, &rem[0])) return r;
     // a stage that removed nothing leaves the depth maps, hence m_vimages (additive pass) and both grids, as they are
-    if (rem[0] > 0) { if (int r = filter_rebuild(e, 1)) return r; }
+    if (rem[0] > 0) { if (int r = filter_rebuild(e, 1, false, false)) return r; }
     e->fstats.exact_patches = e->fstats.patches_in - rem[0];
     HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
     HIPCHK(hipEventRecord(e->fev[2], st));
@@ -994,7 +997,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         e->fstats.exact_view_evals = (int64_t)ev2[1];
     }
     if (int r = apply_kills(e, &rem[1])) return r;
-    if (int r = filter_rebuild(e, 1)) return r;
+    if (int r = filter_rebuild(e, 1, true, true)) return r;
     e->fstats.neighbor_patches = e->fstats.exact_patches - rem[1];
     {                                                                              // filterNeighbor(1)
         if (e->uf_parent.ensure(e->pool.cap)) return MVS_ERR_HIP;                  // reused as the retry list
@@ -1009,7 +1012,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         HIPCHK(hipEventRecord(e->fev[5], st));
     }
     if (int r = apply_kills(e, &rem[2])) return r;
-    if (rem[2] > 0) { if (int r = filter_rebuild(e, 1)) return r; }
+    if (rem[2] > 0) { if (int r = filter_rebuild(e, 1, true, true)) return r; }
     {                                                                              // filterSmallGroups
         int64_t alive = 0;
         if (int r = mvs_engine_num_patches(e, &alive)) return r;
@@ -1020,7 +1023,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         HIPCHK(hipEventRecord(e->fev[7], st));
         if (int r = apply_kills(e, &rem[3])) return r;
     }
-    if (rem[3] > 0) { if (int r = filter_rebuild(e, 1)) return r; }
+    if (rem[3] > 0) { if (int r = filter_rebuild(e, 1, false, false)) return r; }
     if (int r = compact_pool(e)) return r;
     int32_t herr = 0;
     HIPCHK(hipMemcpyAsync(&herr, e->error_flag.p, sizeof herr, hipMemcpyDeviceToHost, st));
