@@ -18,13 +18,21 @@ namespace mvsdev {
 // the accepted ids compacted to its front -- the 3 floats per neighbour filterQuad keeps, stored behind the ids.
 // 2048 slots (at most 7/8 visited) and 576 neighbours fit 9472 B, which with the 768 B of static LDS is 10 KB per wave:
 // 16 waves per CU.  The oracle picks the table size by the same rule (engine_neighbor_order).
+#if MVS_LISTCAP > 16
+// the 32-view build: its dynamic LDS is sized by setRefImage's kept textures (22 KB), so Optim::check's set can be twice as large
+// at no cost -- 32 views x 25 cells x two lists meet many more distinct patches (the oracle's rule: list_cap > 16)
+#define MVS_HASH_CAP 4096
+#define MVS_ROW_CAP 1152
+#define MVS_CHECK_LDS_FLOATS 4672
+#else
 #define MVS_HASH_CAP 2048
 #define MVS_ROW_CAP 576
-#define MVS_SET_LDS_FLOATS(HCAP, RCAP) (((HCAP) > 4 * (RCAP) ? (HCAP) : 4 * (RCAP)) + 64)  // + 20 doubles of filterQuad's normal equations
 #define MVS_CHECK_LDS_FLOATS 2368
+#endif
+#define MVS_SET_LDS_FLOATS(HCAP, RCAP) (((HCAP) > 4 * (RCAP) ? (HCAP) : 4 * (RCAP)) + 64)  // + 20 doubles of filterQuad's normal equations
 static_assert(MVS_SET_LDS_FLOATS(MVS_HASH_CAP, MVS_ROW_CAP) <= MVS_CHECK_LDS_FLOATS, "neighbour search LDS");
-#define MVS_FILTER_HASH_CAP MVS_HASH_CAP   // Filter::filterNeighbor, first launch over all patches: the same limits
-#define MVS_FILTER_ROW_CAP MVS_ROW_CAP
+#define MVS_FILTER_HASH_CAP 2048           // Filter::filterNeighbor, first launch over all patches: the small configuration in both builds
+#define MVS_FILTER_ROW_CAP 576
 #define MVS_FILTER2_HASH_CAP 16384         // second launch over the patches the first could not hold: 64 KB
 #define MVS_FILTER2_ROW_CAP 4096
 DEV int rows_offset(int n) { return (n + 63) & ~63; }  // the rows start behind the ids, on a 256-byte boundary

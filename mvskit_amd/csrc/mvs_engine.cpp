@@ -757,7 +757,11 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     }
 #endif
     if (herr & 3) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
-    if (herr & 4) { g_err = "mvs_engine_pass: Optim::check met more than 1792 patches around one patch, or more than 576 neighbours (engine limit)"; return MVS_ERR_CAPACITY; }
+    if (herr & 4) {
+        g_err = MVS_LISTCAP > 16 ? "mvs_engine_pass: Optim::check met more than 3584 patches around one patch, or more than 1152 neighbours (engine limit)"
+                                 : "mvs_engine_pass: Optim::check met more than 1792 patches around one patch, or more than 576 neighbours (engine limit)";
+        return MVS_ERR_CAPACITY;
+    }
     return MVS_OK;
 }
 

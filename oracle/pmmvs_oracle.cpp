@@ -1173,12 +1173,13 @@ float compute_radius(const Scene& s, const Patch& p) {
  * the neighbours through a hash set of every id it meets in the scanned cell lists (`visited`), an ordered
  * linear-probing table (each key sits behind larger keys only), whose layout does not depend on the order of the
  * insertions: it is the layout of inserting the keys in descending order with plain linear probing.  The accepted ids
- * are taken in slot order.  Table size: 2048 slots while at most 7/8 of them are visited and at most 576 ids are
- * accepted (mvs_check.cuh: MVS_HASH_CAP, MVS_ROW_CAP), else 16384 (Filter::filterNeighbor's second launch). */
-void engine_neighbor_order(std::vector<int> visited, std::vector<int>& nb /* sorted unique in, slot order out */) {
+ * are taken in slot order.  Table size: first_cap slots while at most 7/8 of them are visited and at most first_rows ids
+ * are accepted (mvs_check.cuh: 2048 / 576 -- MVS_HASH_CAP, MVS_ROW_CAP; 4096 / 1152 in Optim::check of the 32-view build),
+ * else 16384 (Filter::filterNeighbor's second launch). */
+void engine_neighbor_order(std::vector<int> visited, std::vector<int>& nb /* sorted unique in, slot order out */, size_t first_cap, size_t first_rows) {
     std::sort(visited.begin(), visited.end());
     visited.erase(std::unique(visited.begin(), visited.end()), visited.end());
-    size_t cap = (visited.size() <= 1792 && nb.size() <= 576) ? 2048 : 16384;
+    size_t cap = (visited.size() <= first_cap / 8 * 7 && nb.size() <= first_rows) ? first_cap : 16384;
     while (visited.size() * 8 > cap * 7) cap *= 2; /* beyond the engine's limits (it reports an error there) */
     std::vector<int> table(cap, -1);
     for (size_t k = visited.size(); k-- > 0;) {
@@ -1193,7 +1194,7 @@ void engine_neighbor_order(std::vector<int> visited, std::vector<int>& nb /* sor
     nb.swap(out);
 }
 
-void find_neighbors(const Scene& s, const Patch& p, std::vector<int>& nb, float scale, int margin, const DestCtx* ctx) {
+void find_neighbors(const Scene& s, const Patch& p, std::vector<int>& nb, float scale, int margin, const DestCtx* ctx, bool in_check = false) {
     std::vector<int> visited;
     const float radius = (float)(1.5 * margin * compute_radius(s, p));
     float unit = 0.0f;
@@ -1222,7 +1223,10 @@ void find_neighbors(const Scene& s, const Patch& p, std::vector<int>& nb, float 
     }
     std::sort(nb.begin(), nb.end());
     nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
-    if (s.cfg.sum_mode == ORC_SUM_TREE64) engine_neighbor_order(visited, nb);
+    if (s.cfg.sum_mode == ORC_SUM_TREE64) {
+        const bool wide = in_check && s.list_cap > 16;  /* the 32-view engine build gives Optim::check a 4096-slot set */
+        engine_neighbor_order(visited, nb, wide ? 4096 : 2048, wide ? 1152 : 576);
+    }
 }
 
 /* Filter::ortho, filter.cpp:394-409 */
@@ -1341,7 +1345,7 @@ int check_patch(const Scene& s, Patch& p, const DestCtx* ctx) {
     p.tmp = gain;
     if (gain < 0.0f) { p.nimg = 0; return 1; }
     std::vector<int> nb;
-    find_neighbors(s, p, nb, 4.0f, 2, ctx);
+    find_neighbors(s, p, nb, 4.0f, 2, ctx, true);
     if (6 < (int)nb.size() && filter_quad(s, p, nb, ctx)) { p.nimg = 0; return 1; }
     return 0;
 }
