@@ -418,3 +418,52 @@ def test_filter_run_matches_oracle(small_multi_scene):
         np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
         o.update_threshold()
         e.update_threshold()
+
+
+RANDOM_CASES = [  # (nviews, W, H, arc, kind, level, csize, wsize, minImageNum, masks, view_propagation, stride, max_propag)
+    (3, 200, 150, 25.0, "plane", 0, 2, 7, 2, False, 0, 4, 2),
+    (4, 224, 160, 40.0, "multi", 0, 1, 5, 2, True, 0, 6, 2),
+    (5, 256, 176, 55.0, "multi", 1, 2, 7, 3, False, 1, 3, 2),
+    (6, 192, 144, 70.0, "multi", 0, 3, 3, 3, True, 0, 2, 1),
+    (7, 160, 112, 60.0, "plane", 0, 2, 6, 4, False, 1, 6, 2),
+    (8, 144, 104, 80.0, "multi", 0, 2, 7, 3, False, 0, 6, 3),
+    (9, 176, 128, 65.0, "multi", 1, 1, 5, 4, True, 0, 3, 2),
+    (10, 160, 120, 75.0, "multi", 0, 2, 4, 5, False, 0, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", range(len(RANDOM_CASES)))
+def test_mixed_configurations(case):
+    """A sweep over the configuration space -- views, image size, arc, pyramid level, cell size, window size, m_minImageNum, masks,
+    view propagation, seed density, MAX_NUM_OF_PROPAG -- each through two or three iterations of PmMvps::run's loop with Optim::check and
+    Filter::run: counters, lists and the removal counts equal to the oracle's, coordinates within the north-star tolerance."""
+    nv, W, H, arc, kind, level, csize, wsize, mi, use_masks, vprop, stride, maxp = RANDOM_CASES[case]
+    sc = synth.make_scene(nviews=nv, W=W, H=H, arc_deg=arc, radius=4.0, kind=kind)
+    seeds = synth.make_seeds(sc, level=level, csize=csize, stride=stride, seed=100 + case)
+    masks = None
+    if use_masks:
+        masks = np.full((nv, H, W), 255, np.uint8)
+        masks[:, : H // 6, :] = 0
+        masks[case % nv, :, : W // 5] = 60
+    o, e = _pair(sc, level=level, csize=csize, wsize=wsize, minImageNum=mi, seed=40 + case, enable_check=1, view_propagation=vprop, max_propag=maxp)
+    if masks is not None:
+        o.set_scene(sc, masks=masks)
+        e.set_scene(sc, masks=masks)
+    o.add_patches(seeds)
+    e.upload_patches(seeds)
+    total = 0
+    for it in range(3 if case < 4 else 2):  # the larger cases stop after the first iteration with Optim::check (the oracle is the slow side)
+        co, ce = o.propagate(it), e.propagate(it)
+        assert co == ce, (case, it, co, ce)
+        total += co["patches"]
+        ro, re_ = o.filter(), e.filter()
+        assert [ro[k] for k in ("outside", "exact", "neighbor", "groups")] == [re_[k] for k in ("outside", "exact", "neighbor", "groups")], (case, it, ro, re_)
+        o.update_threshold()
+        e.update_threshold()
+    assert total > 200, total
+    po, pe = o.patches(), e.patches()
+    assert po.shape == pe.shape and po.shape[0] > 0
+    np.testing.assert_array_equal(po["images"], pe["images"])
+    np.testing.assert_array_equal(po["vimages"], pe["vimages"])
+    np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+    np.testing.assert_allclose(pe["normal"], po["normal"], rtol=0, atol=REL_TOL)
