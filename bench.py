@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--refine-steps", type=int, default=6)  # four proposals per step: 1 + 4 * 6 = 25 cost evaluations per candidate
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--filter", action="store_true", help="BASELINE config 5: run Filter::run (filter.cpp:25-49) after every iteration, inside the timed region")
+    ap.add_argument("--no-config5", dest="config5", action="store_false", help="skip the extra repetition with Filter::run that fills the `config5` block")
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal: run the N>1 code path (RCCL exchange) with a world of 1")
     ap.add_argument("--scene-cache", default=os.path.join("/tmp", "mvskit_scene_cache"))
     return ap.parse_args()
@@ -64,9 +65,30 @@ def spawn_ranks(args) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll all ranks: when one exits non-zero its siblings (possibly waiting for it in a collective) are terminated
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = max(rc, abs(r))
+                log(f"rank process {p.pid} exited with {r}: terminating the other ranks")
+                for q in live:
+                    q.terminate()
+                t_kill = time.time() + 10.0
+                for q in live:
+                    try:
+                        q.wait(timeout=max(0.1, t_kill - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        q.wait()
+                live = []
+                break
     return rc
 
 
@@ -235,13 +257,13 @@ def main():
         host_ms["upload_patches_ms"] = 1000.0 * (time.perf_counter() - t_u0)
         e.set_thresholds(NCC0, NCC_BEFORE0, DEPTH0)
 
-    def step(it):
+    def step(it, with_filter=args.filter):
         ts = time.perf_counter()
         thr = e.thresholds()
         assert 0.6 - 1e-4 <= thr[0] <= 0.7 + 1e-4 and 1 <= thr[2] <= SCHEDULE_ITERS, thr
         c = ex.propagate(it) if ex else e.propagate(it)
         t = dict(ex.last_timing) if ex else e.timing()
-        if args.filter:
+        if with_filter:
             tf = time.perf_counter()
             c["filter_removed"] = e.filter()
             t["filter_ms"] = 1000.0 * (time.perf_counter() - tf)
@@ -249,7 +271,7 @@ def main():
         e.update_threshold()
         if rank == 0:
             log(f"iter {it} (nccThreshold {thr[0]:.2f}, m_depth {thr[2]}): {time.perf_counter() - ts:.3f} s, patches {c['patches']}, candidates {c['candidates']}, "
-                f"view_evals {c['view_evals']}, inserted {c['inserted']}, replaced {c['replaced']}, timing {t}" + (f", filter removed {c['filter_removed']}" if args.filter else ""))
+                f"view_evals {c['view_evals']}, inserted {c['inserted']}, replaced {c['replaced']}, timing {t}" + (f", filter removed {c['filter_removed']}" if with_filter else ""))
         return c, t
 
     # warm-up: W steps of the same schedule
@@ -262,6 +284,8 @@ def main():
     sweep_ms = index_ms = commit_ms = exchange_ms = 0.0
     launches = exchange_bytes = local_view_evals = 0
     patches_by_iter = [0] * SCHEDULE_ITERS
+    sec_by_iter = [0.0] * SCHEDULE_ITERS
+    steps_by_iter = [0] * SCHEDULE_ITERS
     fstats = {}
     pool_after_iter0 = None
     timed = 0.0
@@ -274,6 +298,8 @@ def main():
         c, t = step(it)
         barrier()
         timed += time.perf_counter() - t0
+        sec_by_iter[it] += time.perf_counter() - t0
+        steps_by_iter[it] += 1
         patches += c["patches"]; view_evals += c["view_evals"]; evals += c["evals"]
         patches_by_iter[it] += c["patches"]
         sweep_ms += t["sweep_ms"]; index_ms += t["index_ms"]; commit_ms += t["commit_ms"]; launches += t["sweep_launches"]
@@ -291,6 +317,36 @@ def main():
         sm = tt.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt = float(mx[0]); patches = int(sm[1]); view_evals = int(sm[2])
+    # BASELINE configs[4] ("12-view 1080p with filter.cpp geometric-consistency pass fused on GPU") beside the headline: one more
+    # repetition of the 3-iteration schedule with Filter::run (filter.cpp:25-49) after every iteration, as PmMvps::run has it
+    # (pmmvps.cpp:95-105), on its own clock -- the headline `value` above is not touched by it.
+    cfg5 = None
+    if not args.filter and args.config5:
+        f5 = {}
+        p5 = 0
+        t5 = 0.0
+        f5_ms = 0.0
+        for it in range(SCHEDULE_ITERS):
+            if it == 0:
+                reset_state()
+            barrier()
+            t0 = time.perf_counter()
+            c, t = step(it, True)
+            barrier()
+            t5 += time.perf_counter() - t0
+            p5 += c["patches"]
+            f5_ms += t["filter_ms"]
+            for k, v in c["filter_stats"].items():
+                f5[k] = f5.get(k, 0) + v
+        if world > 1:
+            tt = torch.tensor([t5, float(p5)], dtype=torch.float64, device="cpu" if shared_gpu else device)
+            mx = tt.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            sm = tt.clone()
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            t5 = float(mx[0]); p5 = int(sm[1])
+        cfg5 = (p5, t5, f5, f5_ms)
+
     n_alive = e.num_patches()
     t_d0 = time.perf_counter()
     final_pool = e.patches()  # what a caller takes back over PCIe after the last iteration
@@ -322,9 +378,16 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"the (view, cell) sequence sharded in {world} contiguous ranges over {world} ranks; per colour pass: {exchange}"},
             "patches": patches,
             "patches_by_iteration": patches_by_iter if world == 1 else None,
+            # per iteration of the schedule (mean over the timed steps that ran it): iteration 0 has no Optim::check and is the fast one;
+            # `value_per_repetition` weights the three equally whatever --steps is (with --steps 20 the headline holds 7 / 7 / 6 of them)
+            "ms_by_iteration": [1000.0 * sec_by_iter[i] / max(steps_by_iter[i], 1) for i in range(SCHEDULE_ITERS)],
+            "steps_by_iteration": steps_by_iter,
             "view_evals": view_evals,
             "pool_alive": n_alive,
         }
+        if world == 1 and all(steps_by_iter):
+            out["patches_per_s_by_iteration"] = [patches_by_iter[i] / sec_by_iter[i] for i in range(SCHEDULE_ITERS)]
+            out["value_per_repetition"] = sum(patches_by_iter[i] / steps_by_iter[i] for i in range(SCHEDULE_ITERS)) / sum(sec_by_iter[i] / steps_by_iter[i] for i in range(SCHEDULE_ITERS))
         if sweep_ms > 0:
             alg = local_view_evals * ALG_BYTES_PER_VIEW_EVAL  # rank 0's own launches (= the whole job at N = 1)
             ach = alg / (sweep_ms * 1e-3) / 1e9
@@ -348,26 +411,36 @@ def main():
             if ex is not None:
                 out["roofline"]["rank"] = 0
                 out["exchange"] = {"ms": exchange_ms, "bytes_gathered_per_rank": exchange_bytes, "collective": exchange}
-        if fstats:
+        def filter_roofline(f, calls):
             # Filter::run (filter.cpp:25-49) -- algorithmic bytes per DESIGN.md "Filter::run": what the two heavy stages have to
             # read and write if every datum moves once
-            f = fstats
             ex_bytes = f["exact_patches"] * (128 + 72) + f["exact_view_evals"] * (5 * (8 + 16) + ALG_BYTES_PER_VIEW_EVAL)
             nb_bytes = f["neighbor_patches"] * 128 + f["neighbor_tasks"] * 8 + f["neighbor_entries"] * 4 + f["neighbor_visited"] * 48 + f["neighbor_accepted"] * 32
 
             def blk(ms, nbytes, units, unit_name):
                 gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms": ms,
-                        "algorithmic_bytes": nbytes, unit_name: units, "calls": args.steps}
+                        "algorithmic_bytes": nbytes, unit_name: units, "calls": calls}
 
-            out["roofline_filter"] = {
+            return {
                 "filterExact": blk(f["exact_ms"], ex_bytes, f["exact_patches"], "patches"),
                 "filterNeighbor": blk(f["neighbor_ms"], nb_bytes, f["neighbor_patches"], "patches"),
                 "stage_ms": {k: f[k] for k in ("outside_ms", "exact_ms", "neighbor_ms", "groups_ms", "rebuild_ms", "total_ms")},
-                "counts": {k: f[k] for k in ("patches_in", "exact_view_evals", "neighbor_tasks", "neighbor_entries", "neighbor_visited", "neighbor_accepted")},
-                "note": "per stage: HIP-event time of its kernel(s) summed over the timed steps; bytes = record (128 B) + per surviving view 5 depth-map cells "
+                "ms_per_call": f["total_ms"] / max(calls, 1),
+                "counts": {k: f[k] for k in ("patches_in", "exact_view_evals", "neighbor_tasks", "neighbor_entries", "neighbor_visited", "neighbor_accepted", "neighbor_retried")},
+                "note": "per stage: HIP-event time of its kernel(s) summed over the calls; bytes = record (128 B) + per surviving view 5 depth-map cells "
                         "(8 B) with the patch each names (16 B) + 588 B of setRefImage samples + 72 B of lists written (filterExact); record + 8 B per "
                         "list opened + 4 B per id walked + 48 B per distinct patch met + 32 B per neighbour fitted (filterNeighbor)"}
+
+        if fstats:
+            out["roofline_filter"] = filter_roofline(fstats, args.steps)
+        if cfg5 is not None:
+            p5, t5, f5, f5_ms = cfg5
+            out["config5"] = {"workload": "BASELINE configs[4]: the same scene and schedule, one repetition (3 iterations) with Filter::run (filter.cpp:25-49) after every "
+                                          "iteration inside the timed region, run after the headline loop on its own clock",
+                              "metric": "patches/s (propagate+optim iteration + Filter::run), 12-view 1080p", "value": p5 / t5 if t5 > 0 else 0.0, "unit": "patches/s",
+                              "steps": SCHEDULE_ITERS, "ms_per_step": 1000.0 * t5 / SCHEDULE_ITERS, "patches": p5,
+                              "filter_ms_per_call_host_clock": f5_ms / SCHEDULE_ITERS, "roofline_filter": filter_roofline(f5, SCHEDULE_ITERS)}
         if world == 1 and reps >= 1:
             # what a caller that hands over host buffers sees for ONE 3-iteration job: images and seeds in over PCIe (pyramids built on
             # the device), the three iterations, the patches back out.  Never `value` (inputs resident), reported beside it.

@@ -157,6 +157,7 @@ typedef struct mvs_filter_stats {
     int64_t neighbor_entries;    /* list entries walked (4-byte ids) */
     int64_t neighbor_visited;    /* distinct patches met: one 48-byte geometry gather each */
     int64_t neighbor_accepted;   /* neighbours handed to filterQuad */
+    int64_t neighbor_retried;    /* patches whose neighbourhood did not fit the first launch's id set (second launch, 16384 slots) */
 } mvs_filter_stats;
 int mvs_engine_filter_stats(mvs_engine* e, mvs_filter_stats* out);
 

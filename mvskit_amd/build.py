@@ -51,26 +51,31 @@ def build_engine(force: bool = False, verbose: bool = False, cap32: bool = False
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libmvskit_host.so")
+HOST_LIB32_PATH = os.path.join(LIB_DIR, "libmvskit_host_cap32.so")
 
 
-def build_host(force: bool = False, verbose: bool = False) -> str:
-    """The host-side mirror of the reference classes (C++, g++), linked against the engine's C ABI."""
+def build_host(force: bool = False, verbose: bool = False, cap32: bool = False) -> str:
+    """The host-side mirror of the reference classes (C++, g++), linked against the engine's C ABI -- one host library per
+    engine build: libmvskit_host.so -> libmvskit_engine.so (view lists of 16), libmvskit_host_cap32.so -> the 32-view build."""
+    out = HOST_LIB32_PATH if cap32 else HOST_LIB_PATH
+    eng = LIB32_PATH if cap32 else LIB_PATH
     srcs = [os.path.join(HOST_DIR, "pmmvps_host.cpp"), os.path.join(HOST_DIR, "jpeg_decode.cpp"), os.path.join(HOST_DIR, "ply_read.cpp")]
     deps = srcs + [os.path.join(HOST_DIR, "pmmvps_host.hpp"), os.path.join(HOST_DIR, "jpeg_decode.hpp"), os.path.join(HOST_DIR, "ply_read.hpp"),
-                   os.path.join(ROOT, "include", "mvskit_engine.h"), LIB_PATH]
-    if not force and os.path.exists(HOST_LIB_PATH) and os.environ.get("GRAFT_REPO_ROOT"):
-        return HOST_LIB_PATH
-    if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
-        return HOST_LIB_PATH
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), *srcs, "-o", HOST_LIB_PATH,
-           "-L", LIB_DIR, "-lmvskit_engine", "-Wl,-rpath,$ORIGIN"]
+                   os.path.join(ROOT, "include", "mvskit_engine.h"), eng]
+    if not force and os.path.exists(out) and os.environ.get("GRAFT_REPO_ROOT"):
+        return out
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), *srcs, "-o", out,
+           "-L", LIB_DIR, "-l" + os.path.basename(eng)[3:-3], "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return HOST_LIB_PATH
+    return out
 
 
 if __name__ == "__main__":
     print(build_engine(force=True, verbose=True))
     print(build_engine(force=True, verbose=True, cap32=True))
     print(build_host(force=True, verbose=True))
+    print(build_host(force=True, verbose=True, cap32=True))

@@ -29,12 +29,16 @@ namespace mvsdev {
 #define MVS_ROW_CAP 576
 #define MVS_CHECK_LDS_FLOATS 2368
 #endif
-#define MVS_SET_LDS_FLOATS(HCAP, RCAP) (((HCAP) > 4 * (RCAP) ? (HCAP) : 4 * (RCAP)) + 64)  // + 20 doubles of filterQuad's normal equations
+// the id set (HCAP slots), or -- the accepted ids compacted to its front -- RCAP ids rounded up to 64, 3 floats per neighbour behind them
+// and the 20 doubles of filterQuad's normal equations (+ alignment): whichever is larger
+#define MVS_SET_ROWS_FLOATS(RCAP) ((((RCAP) + 63) & ~63) + 3 * (RCAP) + 64)
+#define MVS_SET_LDS_FLOATS(HCAP, RCAP) ((HCAP) > MVS_SET_ROWS_FLOATS(RCAP) ? (HCAP) : MVS_SET_ROWS_FLOATS(RCAP))
 static_assert(MVS_SET_LDS_FLOATS(MVS_HASH_CAP, MVS_ROW_CAP) <= MVS_CHECK_LDS_FLOATS, "neighbour search LDS");
 #define MVS_FILTER_HASH_CAP 2048           // Filter::filterNeighbor, first launch over all patches: the small configuration in both builds
 #define MVS_FILTER_ROW_CAP 576
-#define MVS_FILTER2_HASH_CAP 16384         // second launch over the patches the first could not hold: 64 KB
-#define MVS_FILTER2_ROW_CAP 4096
+#define MVS_FILTER2_HASH_CAP 16384         // second launch over the patches the first could not hold: exactly 64 KB of dynamic LDS (the
+#define MVS_FILTER2_ROW_CAP 4064           // kernel has no static LDS), which also holds 4096 + 3 * 4064 + 64 dwords of ids, rows and sums
+static_assert(MVS_SET_LDS_FLOATS(MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP) * 4 <= 65536, "the retry launch of Filter::filterNeighbor asks for at most 64 KB");
 DEV int rows_offset(int n) { return (n + 63) & ~63; }  // the rows start behind the ids, on a 256-byte boundary
 
 struct CheckCtx {

@@ -173,8 +173,11 @@ struct mvs_engine {
     ncclComm_t comm = nullptr;
     bool comm_owned = false;
     int comm_rank = 0, comm_world = 1;
-    DevBuf<int64_t> comm_counts;   // [2] mine + [2 * world] gathered
+    DevBuf<int64_t> comm_counts;   // [MVS_XCHG_WORDS] mine + [MVS_XCHG_WORDS * world] gathered
     DevBuf<int32_t> comm_kill_ids; // all ranks' kill ids
+    int pass_status = MVS_OK;      // what the last mvs_engine_pass returned: the exchange carries it to the other ranks
+    std::string pass_error;
+    bool fault_fired = false;      // MVS_FAULT_PASS (fault injection, see pass_impl) fires once per engine
 };
 
 namespace {
@@ -548,12 +551,14 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
         e->vcursor.ensure(nc + 2) || e->dpgrid.ensure(nc + 2) || e->best.ensure(nc + 2) || e->cnt_alive.ensure(nc + 2) || e->vcnt_alive.ensure(nc + 2))
         return MVS_ERR_HIP;
     // Pool capacity: mvs_config.max_patches, else 4 patches per cell (the 1080p runs settle near 1 per cell) -- but never
-    // more than a sixth of the free device memory for each of the two pool buffers: the index, staging and scans grow with it.
+    // more than a sixth of the device's memory for each of the two pool buffers: the index, staging and scans grow with it.
+    // The bound is taken from the TOTAL memory, not from what happens to be free: the ranks of a job must arrive at the same
+    // capacity (what still differs -- an explicit max_patches per rank -- is settled collectively in mvs_engine_exchange).
     int64_t pool_cap = e->cfg.max_patches > 0 ? e->cfg.max_patches : 4 * nc;
     if (e->cfg.max_patches <= 0) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
-            pool_cap = std::max<int64_t>(std::min<int64_t>(pool_cap, (int64_t)(free_b / 6 / sizeof(DPatch))), std::min<int64_t>(pool_cap, nc));
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0)
+            pool_cap = std::max<int64_t>(std::min<int64_t>(pool_cap, (int64_t)(total_b / 6 / sizeof(DPatch))), std::min<int64_t>(pool_cap, nc));
     }
     if (e->pool.ensure(pool_cap) || e->pool_alt.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;
     HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)pool_cap, st));
@@ -682,7 +687,23 @@ int mvs_engine_download_patches(mvs_engine* e, int64_t cap, mvs_patch* out, int6
     return MVS_OK;
 }
 
+// A pass that failed (staging or Optim::check capacity in this rank's shard, a HIP error) leaves its status in the engine:
+// with a communicator attached the next mvs_engine_exchange hands it to every rank, so that all of them give the pass up
+// together instead of waiting in a collective for a rank that has already returned.
+static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out);
 int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
+    const int r = pass_impl(e, iter, pass, out);
+    if (e) { e->pass_status = r; e->pass_error = r ? g_err : std::string(); }
+    return r;
+}
+// forgets a staged pass (after an error): its records are dropped, the eviction flags it set are cleared, the pool is as it
+// was when the pass began (minus the patches the MAX_NUM_OF_PATCHES trim removed, which every rank removes alike)
+static void discard_pass(mvs_engine* e) {
+    if (e->kill.p && e->pool_n > 0) (void)hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    e->staged = false; e->counted = false; e->index_valid = false;
+}
+static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     if (!e || !e->have_views) { g_err = "mvs_engine_pass: views not set"; return MVS_ERR_STATE; }
     if (e->staged) { g_err = "mvs_engine_pass: the previous pass was not committed"; return MVS_ERR_STATE; }
     HIPCHK(hipSetDevice(e->cfg.device));
@@ -710,8 +731,36 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     a.njobs = nj;
     a.job_lo = 0; a.job_hi = nj;
     if (ranged) {
-        a.job_lo = nj * e->cfg.shard_index / e->cfg.shard_count;
-        a.job_hi = nj * (e->cfg.shard_index + 1) / e->cfg.shard_count;
+        // Contiguous ranges of equal WORK, not of equal job count: every rank holds the same index, so every rank computes the
+        // same per-job work proxy (k_job_work), the same prefix sums and the same cuts; rank order stays commit order.  Equal
+        // counts gave each of 8 ranks a band of one and a half views, and such bands differ in work by tens of per cent.
+        // MVS_SPLIT_PROXY=0|1|2 (development): 0 = equal job counts, 1 = source entries, 2 = expected trials by kind (default).
+        const int split_mode = getenv("MVS_SPLIT_PROXY") ? atoi(getenv("MVS_SPLIT_PROXY")) : 2;
+        const int N = e->cfg.shard_count, R = e->cfg.shard_index;
+        std::vector<int32_t> cuts(N + 1, -1);
+        int64_t total_work = 0;
+        if (split_mode > 0 && nj > 0) {
+            const DParams p0 = current_params(e);
+            int shift = 0;  // the scan is 32-bit: scale the proxy down if its worst case would not fit
+            while ((((int64_t)3 * e->prm.cap * e->prm.max_propag * 32 * nj) >> shift) >= (int64_t)INT32_MAX) ++shift;
+            mvsk_job_work(p0, a, split_mode, shift, e->job_cnt.p, st);
+            mvsk_exclusive_scan(e->job_cnt.p, e->job_base_scan.p, nj, e->scan_tmp.p, st);
+            if (int r = e->tmp_i.ensure(N + 1)) return r;
+            HIPCHK(hipMemsetAsync(e->tmp_i.p, 0xff, (size_t)(N + 1) * sizeof(int32_t), st));
+            mvsk_job_cuts(e->job_base_scan.p, nj, N, e->tmp_i.p, st);
+            int32_t tw = 0;
+            HIPCHK(hipMemcpyAsync(cuts.data(), e->tmp_i.p, (size_t)(N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&tw, e->job_base_scan.p + nj, sizeof tw, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            total_work = tw;
+        }
+        cuts[0] = 0; cuts[N] = (int32_t)nj;
+        for (int r = 1; r < N; ++r) {
+            if (total_work <= 0 || cuts[r] < 0) cuts[r] = (int32_t)(nj * r / N);  // no work anywhere: equal counts
+            cuts[r] = std::max(cuts[r], cuts[r - 1]);
+        }
+        a.job_lo = cuts[R];
+        a.job_hi = cuts[R + 1];
         HIPCHK(hipMemsetAsync(e->job_nstage.p, 0, (size_t)nj * sizeof(int32_t), st));  // jobs of other shards stage nothing
     }
     a.staging = e->staging.p; a.staging_cap = e->staging.cap;
@@ -756,6 +805,16 @@ int mvs_engine_pass(mvs_engine* e, int iter, int pass, mvs_counters* out) {
         fprintf(stderr, "  (wave cycles %.3e; max visited %llu, max neighbours %llu)\n", (double)hc.stage[0], hc.stage[12], hc.stage[13]);
     }
 #endif
+    // Fault injection: MVS_FAULT_PASS=<shard>:<iter>:<pass> makes that one pass of that shard report a
+    // capacity failure after its sweep, once -- how the tests drive a rank-local failure through the collective status word.
+    if (const char* f = getenv("MVS_FAULT_PASS")) {
+        int fr = -1, fi = -1, fp = -1;
+        if (!e->fault_fired && sscanf(f, "%d:%d:%d", &fr, &fi, &fp) == 3 && fr == (e->cfg.shard_count > 1 ? e->cfg.shard_index : 0) && fi == iter && fp == pass) {
+            e->fault_fired = true;
+            g_err = "mvs_engine_pass: capacity failure injected by MVS_FAULT_PASS";
+            return MVS_ERR_CAPACITY;
+        }
+    }
     if (herr & 3) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
     if (herr & 4) {
         g_err = MVS_LISTCAP > 16 ? "mvs_engine_pass: Optim::check met more than 3584 patches around one patch, or more than 1152 neighbours (engine limit)"
@@ -874,46 +933,79 @@ int mvs_engine_comm_release(mvs_engine* e) {
     return MVS_OK;
 }
 
+#define MVS_XCHG_WORDS 5  // what a rank tells the others before anything is moved: {new records, evicted ids, status, pool headroom, kill-id capacity}
 int mvs_engine_exchange(mvs_engine* e) {
-    if (!e || !e->staged) { g_err = "mvs_engine_exchange: no pass to exchange"; return MVS_ERR_STATE; }
+    if (!e) { g_err = "mvs_engine_exchange: null engine"; return MVS_ERR_ARG; }
     if (!e->comm) { g_err = "mvs_engine_exchange: no communicator (mvs_engine_comm_init / _attach)"; return MVS_ERR_STATE; }
+    if (!e->staged && e->pass_status == MVS_OK) { g_err = "mvs_engine_exchange: no pass to exchange"; return MVS_ERR_STATE; }
     HIPCHK(hipSetDevice(e->cfg.device));
     hipStream_t st = e->stream;
     const Rccl& R = rccl();
     const int world = e->comm_world, rank = e->comm_rank;
     Range rg("mvs:exchange");
-    HIPCHK(hipEventRecord(e->ev[4], st));
-    if (int r = ensure_counts(e)) return r;
-    // (1) counts: one all-gather of {n_new, n_kill} per rank
-    if (int r = e->comm_counts.ensure(2 + 2 * (int64_t)world)) return r;
-    const int64_t mine[2] = {e->n_new, e->n_kill};
-    std::vector<int64_t> all(2 * (size_t)world);
+    // (0) everything that can fail on this rank alone happens BEFORE the first collective and ends up in a status word
+    int local = e->pass_status;
+    std::string local_err = e->pass_error;
+    auto fail_local = [&](int r) { if (local == MVS_OK) { local = r; local_err = g_err; } };
+    if (hipEventRecord(e->ev[4], st) != hipSuccess) { g_err = "mvs_engine_exchange: hipEventRecord failed"; fail_local(MVS_ERR_HIP); }
+    if (local == MVS_OK) { if (int r = ensure_counts(e)) fail_local(r); }
+    if (int r = e->comm_counts.ensure(MVS_XCHG_WORDS * (1 + (int64_t)world))) fail_local(r);
+    // the evicted ids of all ranks (a rank evicts pool patches from its own cells only, but a patch sits in the cells of several
+    // views, so the union may name an id twice): one allocation of pool-capacity ids, the limit agreed as the minimum over the ranks
+    if (int r = e->comm_kill_ids.ensure(std::max<int64_t>(e->pool.cap, 1024))) fail_local(r);
+    if (!e->comm_counts.p) return MVS_ERR_HIP;  // not even the status word can be sent: nothing left to agree on
+    if (local != MVS_OK) { e->n_new = 0; e->n_kill = 0; }
+    // (1) one all-gather of MVS_XCHG_WORDS int64 per rank
+    const int64_t mine[MVS_XCHG_WORDS] = {e->n_new, e->n_kill, (int64_t)local, e->pool.cap - e->pool_n, e->comm_kill_ids.cap};
+    std::vector<int64_t> all(MVS_XCHG_WORDS * (size_t)world);
     HIPCHK(hipMemcpyAsync(e->comm_counts.p, mine, sizeof mine, hipMemcpyHostToDevice, st));
-    NCCLCHK(R.AllGather(e->comm_counts.p, e->comm_counts.p + 2, 2, ncclInt64, e->comm, st));
-    HIPCHK(hipMemcpyAsync(all.data(), e->comm_counts.p + 2, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    NCCLCHK(R.AllGather(e->comm_counts.p, e->comm_counts.p + MVS_XCHG_WORDS, MVS_XCHG_WORDS, ncclInt64, e->comm, st));
+    HIPCHK(hipMemcpyAsync(all.data(), e->comm_counts.p + MVS_XCHG_WORDS, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     std::vector<int64_t> off_new(world + 1, 0), off_kill(world + 1, 0);
-    for (int r = 0; r < world; ++r) { off_new[r + 1] = off_new[r] + all[2 * r]; off_kill[r + 1] = off_kill[r] + all[2 * r + 1]; }
+    int64_t headroom = INT64_MAX, kill_cap = INT64_MAX;
+    int bad_rank = -1, bad_status = MVS_OK;
+    for (int r = 0; r < world; ++r) {
+        const int64_t* w = &all[MVS_XCHG_WORDS * (size_t)r];
+        off_new[r + 1] = off_new[r] + w[0]; off_kill[r + 1] = off_kill[r] + w[1];
+        if (w[2] != MVS_OK && bad_rank < 0) { bad_rank = r; bad_status = (int)w[2]; }
+        headroom = std::min(headroom, w[3]); kill_cap = std::min(kill_cap, w[4]);
+    }
     const int64_t tot_new = off_new[world], tot_kill = off_kill[world];
-    if (all[2 * rank] != e->n_new || all[2 * rank + 1] != e->n_kill) { g_err = "mvs_engine_exchange: count all-gather returned other values for this rank"; return MVS_ERR_STATE; }
-    if (e->pool_n + tot_new > e->pool.cap) {  // every rank sees the same totals and fails alike
-        g_err = "mvs_engine_exchange: patch pool capacity exceeded (raise mvs_config.max_patches)";
+    // every rank sees the same words and takes the same way out: the pass is given up everywhere, nobody waits
+    if (bad_rank >= 0) {
+        discard_pass(e);
+        e->pass_status = MVS_OK;
+        if (bad_rank == rank) g_err = local_err.empty() ? std::string("mvs_engine_exchange: this rank's pass failed") : local_err;
+        else g_err = "mvs_engine_exchange: rank " + std::to_string(bad_rank) + " reported status " + std::to_string(bad_status) + " for this pass; all ranks give it up";
+        return bad_status;
+    }
+    if (all[MVS_XCHG_WORDS * (size_t)rank] != e->n_new || all[MVS_XCHG_WORDS * (size_t)rank + 1] != e->n_kill) {
+        g_err = "mvs_engine_exchange: count all-gather returned other values for this rank"; return MVS_ERR_STATE;
+    }
+    if (tot_new > headroom || tot_kill > kill_cap) {  // decided on the minimum over the ranks: all fail alike, whatever their own capacity
+        discard_pass(e);
+        g_err = "mvs_engine_exchange: patch pool capacity exceeded on at least one rank (raise mvs_config.max_patches)";
         return MVS_ERR_CAPACITY;
     }
-    if (int r = e->comm_kill_ids.ensure(std::max<int64_t>(tot_kill, 16))) return r;
     // (2) this rank's block goes straight to its final place behind the pool, (3) every block is broadcast in place.
     // Job ranges are contiguous and ascending in rank, so the concatenation in rank order is the global
     // (view, cell, creation) order of the 1-GPU commit.
     DPatch* tail = e->pool.p + e->pool_n;
     if (e->n_new > 0) mvsk_commit_copy(e->sa, e->job_base_scan.p, tail + off_new[rank], e->n_new, nullptr, 0, st);
     if (e->n_kill > 0) mvsk_kill_export(e->kill.p, e->pool_n, e->kill_base.p, e->comm_kill_ids.p + off_kill[rank], e->n_kill, st);
-    NCCLCHK(R.GroupStart());
-    for (int r = 0; r < world; ++r) {
-        const int64_t nn = all[2 * r], nk = all[2 * r + 1];
-        if (nn > 0) NCCLCHK(R.Broadcast(tail + off_new[r], tail + off_new[r], (size_t)nn * sizeof(DPatch), ncclUint8, r, e->comm, st));
-        if (nk > 0) NCCLCHK(R.Broadcast(e->comm_kill_ids.p + off_kill[r], e->comm_kill_ids.p + off_kill[r], (size_t)nk, ncclInt32, r, e->comm, st));
+    {
+        // an error inside the group still closes it (a group left open would swallow every later call of this thread)
+        ncclResult_t first = R.GroupStart();
+        for (int r = 0; r < world && first == ncclSuccess; ++r) {
+            const int64_t nn = all[MVS_XCHG_WORDS * (size_t)r], nk = all[MVS_XCHG_WORDS * (size_t)r + 1];
+            if (nn > 0) first = R.Broadcast(tail + off_new[r], tail + off_new[r], (size_t)nn * sizeof(DPatch), ncclUint8, r, e->comm, st);
+            if (nk > 0 && first == ncclSuccess) first = R.Broadcast(e->comm_kill_ids.p + off_kill[r], e->comm_kill_ids.p + off_kill[r], (size_t)nk, ncclInt32, r, e->comm, st);
+        }
+        const ncclResult_t end = R.GroupEnd();
+        if (first == ncclSuccess) first = end;
+        if (first != ncclSuccess) { g_err = std::string("mvs_engine_exchange: record / kill-id broadcast: ") + R.GetErrorString(first); return MVS_ERR_HIP; }
     }
-    NCCLCHK(R.GroupEnd());
     HIPCHK(hipEventRecord(e->ev[5], st));
     // commit of the union (the same on every rank)
     {
@@ -930,7 +1022,7 @@ int mvs_engine_exchange(mvs_engine* e) {
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, e->ev[4], e->ev[5]); e->timing.exchange_ms = ms;
     (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->timing.commit_ms = ms;
-    e->timing.exchange_bytes = (tot_new - e->n_new) * (int64_t)sizeof(DPatch) + (tot_kill - e->n_kill) * 4 + 16 * (int64_t)(world - 1);
+    e->timing.exchange_bytes = (tot_new - e->n_new) * (int64_t)sizeof(DPatch) + (tot_kill - e->n_kill) * 4 + 8 * MVS_XCHG_WORDS * (int64_t)(world - 1);
     e->staged = false; e->counted = false; e->index_valid = false;
     return MVS_OK;
 }
@@ -942,9 +1034,13 @@ int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out) {  // Propa
     for (int pass = 0; pass < 2; ++pass) {
         mvs_counters c;
         memset(&c, 0, sizeof c);
-        if (int r = mvs_engine_pass(e, iter, pass, &c)) return r;
-        if (e->comm) { if (int r = mvs_engine_exchange(e)) return r; }
-        else if (int r = mvs_engine_commit_local(e)) return r;
+        const int rp = mvs_engine_pass(e, iter, pass, &c);
+        if (e && e->comm) {  // the exchange is reached whatever the pass returned: it is where the ranks agree on a failure
+            if (int r = mvs_engine_exchange(e)) return r;
+        } else {
+            if (rp) { if (e && e->staged) { const std::string keep = g_err; discard_pass(e); g_err = keep; } return rp; }
+            if (int r = mvs_engine_commit_local(e)) return r;
+        }
         add_counters(total, c);
         tt.index_ms += e->timing.index_ms; tt.sweep_ms += e->timing.sweep_ms; tt.commit_ms += e->timing.commit_ms; tt.sweep_launches += 1;
         tt.exchange_ms += e->timing.exchange_ms; tt.exchange_bytes += e->timing.exchange_bytes;
@@ -1012,7 +1108,10 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         int32_t nr = 0;
         HIPCHK(hipMemcpyAsync(&nr, nretry, sizeof nr, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+        e->fstats.neighbor_retried = nr;
         mvsk_filter_neighbor_retry(current_params(e), e->kill.p, e->uf_parent.p, nr, e->error_flag.p, e->fstat_buf.p, st);
+        HIPCHK(hipGetLastError());  // a refused launch (LDS request) must not pass for "nothing to filter"
         HIPCHK(hipEventRecord(e->fev[5], st));
     }
     if (int r = apply_kills(e, &rem[2])) return r;

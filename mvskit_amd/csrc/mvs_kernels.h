@@ -19,6 +19,8 @@ void mvsk_map_extract(const DParams& prm, int view, int kind, const unsigned lon
 void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st);
 size_t mvsk_sweep_lds_bytes(const DParams& prm);
 void mvsk_sweep(const DParams& prm, const SweepArgs& a, hipStream_t st);
+void mvsk_job_work(const DParams& prm, const SweepArgs& a, int mode, int shift, int32_t* work, hipStream_t st);
+void mvsk_job_cuts(const int32_t* scan, int64_t njobs, int n, int32_t* cuts, hipStream_t st);
 void mvsk_commit_count(const SweepArgs& a, int32_t* cnt, hipStream_t st);
 void mvsk_commit_copy(const SweepArgs& a, const int32_t* base, DPatch* dst, int64_t dst_cap, int32_t* per_view, int keep_key, hipStream_t st);
 void mvsk_kill_count(const uint8_t* kill, int64_t n, int32_t* cnt, hipStream_t st);

@@ -290,6 +290,62 @@ __global__ __launch_bounds__(64) void k_fill_ncc(DParams prm, unsigned long long
 // turned inside out: the cell gathers from the cell above/below and the cell beside it, in the order the
 // raster sweep would reach them, and runs Propagate::propagatePatch (propagate.cpp:126-218) on its own list.
 DEV bool rank_before(float na, int a, float nb, int b) { return (na != nb) ? (na > nb) : (a < b); }
+// job -> (swept view, destination cell): one job per (view, row, half column) of the pass colour
+DEV void job_cell(const DParams& prm, const SweepArgs& a, int64_t job, int& v, int& cx, int& cy) {
+    int s = 0;
+    while (s + 1 < a.nsweep_views && job >= a.job_base[s + 1]) ++s;
+    v = a.sweep_views[s];
+    const int gw = (prm.views + v)->gw, halfw = (gw + 1) / 2;
+    const int local = (int)(job - a.job_base[s]);
+    cy = local / halfw;
+    cx = 2 * (local % halfw) + ((a.colour + cy) & 1);
+}
+// Work proxy of a job, for cutting the job sequence into ranges of equal WORK (multi-GPU: every rank holds the same index,
+// computes the same proxy and finds the same cuts).  A job runs max_propag trials per source entry whose reference view is
+// the swept view (propagate.cpp:102-108); a trial into a cell that still has room runs the whole pipeline (preProcess,
+// refinePatch's 25 evaluations, postProcess, check), a trial into a full cell one evaluation and, mostly, the pre-filter
+// (propagate.cpp:166-173); about four trials in five that run the pipeline add a patch to the cell.
+// mode 1: source entries alone; mode 2: 32 per expected pipeline trial + 2 per expected pre-filter trial.
+__global__ void k_job_work(DParams prm, SweepArgs a, int mode, int shift, int32_t* __restrict__ work) {
+    const int64_t job = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= a.njobs) return;
+    int v, cx, cy;
+    job_cell(prm, a, job, v, cx, cy);
+    const DView* vw = prm.views + v;
+    const int gw = vw->gw, gh = vw->gh;
+    int w = 0;
+    if (cx < gw && cy < gh) {
+        const int sxs[3] = {cx, cx - a.inc, cx}, sys[3] = {cy - a.inc, cy, cy};
+        const int nsrc = prm.view_propagation ? 3 : 2;
+        int n = 0;
+        for (int k = 0; k < nsrc; ++k) {
+            if (sxs[k] < 0 || gw <= sxs[k] || sys[k] < 0 || gh <= sys[k]) continue;
+            const int g = vw->cell_base + sys[k] * gw + sxs[k];
+            const CellEntry* se = prm.csr_fat + prm.csr_start[g];
+            const int sn = prm.csr_cnt[g];
+            for (int j = 0; j < sn; ++j) n += ((se[j].ref == v) != (k == 2)) ? 1 : 0;
+        }
+        if (mode == 1) w = n;
+        else {
+            const int trials = n * prm.max_propag;
+            const int room = max(prm.cap - prm.csr_cnt[vw->cell_base + cy * gw + cx], 0);
+            const int full = min(trials, (room * 5 + 3) / 4);
+            w = 32 * full + 2 * (trials - full);
+        }
+    }
+    work[job] = (w + (1 << shift) - 1) >> shift;
+}
+// cuts[r] = first job whose inclusive work prefix exceeds total * r / n (r = 1 .. n-1): exactly one job qualifies per r
+__global__ void k_job_cuts(const int32_t* __restrict__ scan, int64_t njobs, int n, int32_t* __restrict__ cuts) {
+    const int64_t job = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= njobs) return;
+    const long long total = scan[njobs], p0 = scan[job], p1 = scan[job + 1];
+    if (p0 == p1) return;
+    for (int r = 1; r < n; ++r) {
+        const long long target = total * r / n;
+        if (p0 <= target && target < p1) cuts[r] = (int32_t)job;
+    }
+}
 
 #if !defined(MVS_SWEEP_WAVES) && MVS_LISTCAP > 16
 // the 32-view build: 22 KB of LDS per wave allow 7 waves per CU whatever the registers, so the allocator gets the 256 VGPRs of
@@ -327,14 +383,10 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
     const int64_t job = a.job_lo + (int64_t)(blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
 #endif
     if (job >= a.job_hi) return;
-    int s = 0;
-    while (s + 1 < a.nsweep_views && job >= a.job_base[s + 1]) ++s;
-    const int v = a.sweep_views[s];
+    int v, cx, cy;
+    job_cell(prm, a, job, v, cx, cy);
     const DView* vw = prm.views + v;
-    const int gw = vw->gw, gh = vw->gh, halfw = (gw + 1) / 2;
-    const int local = (int)(job - a.job_base[s]);
-    const int cy = local / halfw, bx = local % halfw;
-    const int cx = 2 * bx + ((a.colour + cy) & 1);
+    const int gw = vw->gw, gh = vw->gh;
     WaveCtx wc = make_wave_ctx(prm);
     if (wc.lane == 0) a.job_nstage[job] = 0;
     if (cx >= gw || cy >= gh) return;
@@ -701,7 +753,7 @@ template <int HCAP, int RCAP>
 __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* retry, int32_t* nretry,
                                                         int32_t* overflow, unsigned long long* stats /* [1024][4], spread over blocks */) {
     extern __shared__ float s_lds[];
-    __shared__ int s_dummy[1];
+    int* const s_dummy = reinterpret_cast<int*>(s_lds);  // the live list of a destination cell: none here (live_view = -1), never read
     const int64_t id = todo ? (blockIdx.x < (unsigned)ntodo ? todo[blockIdx.x] : -1) : (int64_t)blockIdx.x;
     if (id < 0 || id >= prm.pool_n) return;
     const DPatch* p = prm.pool + id;
@@ -914,6 +966,12 @@ void mvsk_sweep(const DParams& prm, const SweepArgs& a, hipStream_t st) {
     const int64_t nblocks = chunk * 8;
 #endif
     hipLaunchKernelGGL(k_sweep, dim3((unsigned)nblocks), dim3(64), mvsk_sweep_lds_bytes(prm) + pad, st, prm, a);
+}
+void mvsk_job_work(const DParams& prm, const SweepArgs& a, int mode, int shift, int32_t* work, hipStream_t st) {
+    if (a.njobs > 0) hipLaunchKernelGGL(k_job_work, dim3(nblk(a.njobs, 256)), dim3(256), 0, st, prm, a, mode, shift, work);
+}
+void mvsk_job_cuts(const int32_t* scan, int64_t njobs, int n, int32_t* cuts, hipStream_t st) {
+    if (njobs > 0) hipLaunchKernelGGL(k_job_cuts, dim3(nblk(njobs, 256)), dim3(256), 0, st, scan, njobs, n, cuts);
 }
 void mvsk_commit_count(const SweepArgs& a, int32_t* cnt, hipStream_t st) { hipLaunchKernelGGL(k_commit_count, dim3(nblk(a.njobs, 256)), dim3(256), 0, st, a, cnt); }
 void mvsk_commit_copy(const SweepArgs& a, const int32_t* base, DPatch* dst, int64_t dst_cap, int32_t* per_view, int keep_key, hipStream_t st) {

@@ -57,11 +57,15 @@ class Timing(C.Structure):
 class FilterStats(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("outside_ms", "exact_ms", "neighbor_ms", "groups_ms", "rebuild_ms", "total_ms")] + \
                [(n, C.c_int64) for n in ("patches_in", "exact_patches", "exact_view_evals", "neighbor_patches", "neighbor_tasks", "neighbor_entries",
-                                         "neighbor_visited", "neighbor_accepted")]
+                                         "neighbor_visited", "neighbor_accepted", "neighbor_retried")]
 
 
 class EngineError(RuntimeError):
-    pass
+    """A call of the C ABI returned a negative mvs_status (`status`; include/mvskit_engine.h)."""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
 
 
 _libs = {}
@@ -146,7 +150,7 @@ class Engine:
 
     def _check(self, status):
         if status != 0:
-            raise EngineError(f"mvskit engine error {status}: {self.L.mvs_last_error().decode()}")
+            raise EngineError(f"mvskit engine error {status}: {self.L.mvs_last_error().decode()}", status)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

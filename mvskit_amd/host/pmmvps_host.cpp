@@ -168,7 +168,8 @@ int Photo::readPbmMask(const string mname) {
     return 0;
 }
 
-int PhotoSet::init(const vector<int>& images, const string prefix, const int nimages, const int nillums, const int, const int, const int) {
+void PhotoSet::init(const vector<int>& images, const string prefix, const int nimages, const int nillums, const int, const int, const int) {
+    m_status = 0;
     m_images = images; m_nimages = nimages; m_nillums = nillums; m_prefix = prefix;  // photoSet.cpp:20-61
     for (int i = 0; i < m_nimages; ++i) m_dict[images[i]] = i;
     m_photos.assign(m_nimages, Photo());
@@ -177,17 +178,16 @@ int PhotoSet::init(const vector<int>& images, const string prefix, const int nim
         snprintf(iname, sizeof iname, "%simage/%04d%04d.ppm", prefix.c_str(), i, 0);
         snprintf(mname, sizeof mname, "%smask/%08d.pgm", prefix.c_str(), i);
         snprintf(cname, sizeof cname, "%stxt/%08d.txt", prefix.c_str(), i);
-        if (m_photos[i].initCamera(cname) != 0) return -1;
+        if (m_photos[i].initCamera(cname) != 0) { m_status = -1; return; }
         if (m_photos[i].readPpm(iname) != 0) {  // Image::completeName (image.cpp:51-74): <name>.ppm if it exists, else <name>.jpg
             snprintf(iname, sizeof iname, "%simage/%04d%04d.jpg", prefix.c_str(), i, 0);
-            if (m_photos[i].readJpeg(iname) != 0) { cerr << "Unsupported image format found (binary PPM or JPEG): " << iname << endl; return -1; }
+            if (m_photos[i].readJpeg(iname) != 0) { cerr << "Unsupported image format found (binary PPM or JPEG): " << iname << endl; m_status = -1; return; }
         }
         if (m_photos[i].readPgmMask(mname) != 0) {  // Image::alloc tries .pgm, then .pbm (image.cpp:143-147)
             snprintf(mname, sizeof mname, "%smask/%08d.pbm", prefix.c_str(), i);
             (void)m_photos[i].readPbmMask(mname);
         }
     }
-    return 0;
 }
 void PhotoSet::setPhoto(int index, int width, int height, const float P[12], const unsigned char* rgb, const unsigned char* mask) {
     if ((int)m_photos.size() <= index) m_photos.resize(index + 1);
@@ -607,6 +607,14 @@ int PmMvps::createEngine(float maxAngle, float quad) {
     cfg.enable_check = 1;  // Optim::check from m_depth >= 2 (optim.cpp:292)
     cfg.device = m_device;
     if (m_world > 1 || !m_commIdFile.empty()) { cfg.shard_index = m_rank; cfg.shard_count = m_world; }
+    // the reference's m_images / m_vimages are unbounded (optim.cpp:165-205); this library is linked against ONE build of the
+    // engine, whose lists hold mvs_list_cap() views: a data set with more views belongs to the next build of the pair
+    // (libmvskit_host_cap32.so / _cap64.so link libmvskit_engine_cap32.so / _cap64.so), else its lists are cut short
+    if (m_nimages > mvs_list_cap()) {
+        cerr << "PmMvps::init: " << m_nimages << " views, but this build keeps " << mvs_list_cap()
+             << " views per patch list: use the host library built for the larger engine (cap32: up to 32 views, cap64: up to 64)" << endl;
+        if (m_strictListCap) return MVS_ERR_ARG;
+    }
     int r = mvs_engine_create(&cfg, &m_engine);
     if (r != 0) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
     vector<mvs_view_desc> views(m_nimages);
@@ -628,26 +636,42 @@ void PmMvps::setRanks(int rank, int world, const string& idFile, int device) {
 }
 // The communicator id travels through a file: rank 0 writes it (temporary name + rename, so a reader never sees half of
 // it), the other ranks wait for the file.  ncclCommInitRank inside mvs_engine_comm_init is the rendezvous itself.
+// A file left behind by an earlier job must not be taken for this job's: the file carries, ahead of the id, a magic word
+// and the job nonce (PmMvps::m_jobNonce -- MVS_JOB_NONCE in the environment, the same on every rank of a job, e.g. the
+// launcher's job id; without one, the file's age decides: anything older than the reader's own start is stale), and rank 0
+// removes the file once its communicator stands -- by then every rank has read it, or ncclCommInitRank would not have returned.
+namespace {
+struct IdFile { char magic[8]; unsigned long long nonce; long long written_ns; unsigned char id[MVS_COMM_ID_BYTES]; };
+long long wall_ns() { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count(); }
+}
 int PmMvps::joinRanks() {
     if (m_commIdFile.empty()) return 0;
-    unsigned char id[MVS_COMM_ID_BYTES];
+    if (m_jobNonce == 0) { if (const char* n = getenv("MVS_JOB_NONCE")) m_jobNonce = std::strtoull(n, nullptr, 0); }
+    IdFile f;
+    memset(&f, 0, sizeof f);
     if (m_rank == 0) {
-        if (int r = mvs_comm_unique_id(id)) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
+        std::remove(m_commIdFile.c_str());  // whatever an earlier job left there
+        if (int r = mvs_comm_unique_id(f.id)) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
+        memcpy(f.magic, "MVSKCID1", 8); f.nonce = m_jobNonce; f.written_ns = wall_ns();
         const string tmp = m_commIdFile + ".tmp";
         std::ofstream o(tmp.c_str(), std::ios::binary);
-        o.write(reinterpret_cast<const char*>(id), sizeof id);
+        o.write(reinterpret_cast<const char*>(&f), sizeof f);
         o.close();
         if (!o || std::rename(tmp.c_str(), m_commIdFile.c_str()) != 0) { cerr << "PmMvps::init: cannot write " << m_commIdFile << endl; return MVS_ERR_ARG; }
     } else {
+        const long long started = m_startedNs ? m_startedNs : wall_ns() - 60ll * 1000000000ll;  // ranks of one job start within a minute of each other
         bool got = false;
         for (int tries = 0; tries < 1200 && !got; ++tries) {  // up to two minutes
             std::ifstream i(m_commIdFile.c_str(), std::ios::binary);
-            if (i.is_open() && i.read(reinterpret_cast<char*>(id), sizeof id) && i.gcount() == (std::streamsize)sizeof id) got = true;
+            IdFile g;
+            if (i.is_open() && i.read(reinterpret_cast<char*>(&g), sizeof g) && i.gcount() == (std::streamsize)sizeof g && memcmp(g.magic, "MVSKCID1", 8) == 0 &&
+                (m_jobNonce != 0 ? g.nonce == m_jobNonce : g.written_ns >= started)) { f = g; got = true; }
             else std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
-        if (!got) { cerr << "PmMvps::init: no communicator id in " << m_commIdFile << endl; return MVS_ERR_STATE; }
+        if (!got) { cerr << "PmMvps::init: no communicator id of this job in " << m_commIdFile << endl; return MVS_ERR_STATE; }
     }
-    if (int r = mvs_engine_comm_init(m_engine, id, m_rank, m_world)) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
+    if (int r = mvs_engine_comm_init(m_engine, f.id, m_rank, m_world)) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
+    if (m_rank == 0) std::remove(m_commIdFile.c_str());
     return 0;
 }
 
@@ -676,8 +700,9 @@ void PmMvps::init(const Option& option, const PhotoSet& photos) {  // pmmvps.cpp
 }
 void PmMvps::init(const Option& option) {
     PhotoSet ps;
-    if (option.m_status != 0 ||
-        ps.init(option.m_images, option.m_prefix, option.m_nimages, option.m_nillums, option.m_level + 3, option.m_wsize, 1) != 0) { m_status = MVS_ERR_ARG; return; }
+    if (option.m_status != 0) { m_status = MVS_ERR_ARG; return; }
+    ps.init(option.m_images, option.m_prefix, option.m_nimages, option.m_nillums, option.m_level + 3, option.m_wsize, 1);
+    if (ps.m_status != 0) { m_status = MVS_ERR_ARG; return; }
     init(option, ps);
 }
 void PmMvps::updateThreshold() { m_nccThreshold -= 0.05f; m_nccThresholdBefore -= 0.05f; m_countThreshold1 = 2; }
@@ -859,7 +884,8 @@ extern "C" long long mvshost_seeds_from_plys(const char* prefix, long long cap, 
     PmMvps pmmvps;
     pmmvps.m_images = option.m_images; pmmvps.m_nimages = option.m_nimages; pmmvps.m_prefix = option.m_prefix;
     pmmvps.m_level = option.m_level; pmmvps.m_csize = option.m_csize;
-    if (pmmvps.m_photoSet.init(option.m_images, option.m_prefix, option.m_nimages, option.m_nillums, option.m_level + 3, option.m_wsize, 1) != 0) return -2;
+    pmmvps.m_photoSet.init(option.m_images, option.m_prefix, option.m_nimages, option.m_nillums, option.m_level + 3, option.m_wsize, 1);
+    if (pmmvps.m_photoSet.m_status != 0) return -2;
     pmmvps.m_dnInit.init(option.m_prefix, option.m_nimages + 1);
     pmmvps.m_dnInit.m_isTest = 0;
     vector<Ppatch> pp;

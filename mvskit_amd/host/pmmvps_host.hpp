@@ -67,7 +67,9 @@ struct Photo {
 // image/photoSet.hpp:23-62
 class PhotoSet {
 public:
-    int init(const vector<int>& images, const string prefix, const int nimages, const int nillums, const int maxLevel, const int size, const int alloc);
+    // photoSet.hpp:23 (void there too; where the reference exit(1)s on an unreadable camera or image, m_status becomes -1)
+    void init(const vector<int>& images, const string prefix, const int nimages, const int nillums, const int maxLevel, const int size, const int alloc);
+    int m_status = 0;
     // in-memory injection (synthetic scenes)
     void setPhoto(int index, int width, int height, const float P[12], const unsigned char* rgb, const unsigned char* mask);
     int getWidth(const int index, const int level) const { return m_photos[index].m_width >> level; }
@@ -208,6 +210,9 @@ public:
     void setRanks(int rank, int world, const string& idFile, int device = -1);
     int m_rank = 0, m_world = 1, m_device = 0;
     string m_commIdFile;
+    unsigned long long m_jobNonce = 0;  // the same on every rank of a job (0: MVS_JOB_NONCE from the environment, else the id file's age decides)
+    long long m_startedNs = 0;          // wall clock when this rank's job began (0: a minute before joinRanks)
+    bool m_strictListCap = false;       // true: init fails when the data set has more views than the linked engine's lists hold
 
     int m_nimages = 0, m_nillums = 1;
     vector<int> m_images;

@@ -154,6 +154,75 @@ def test_c_abi_exchange_ranks_equal_one_rank(tmp_path, world):
             np.testing.assert_array_equal(p[f], single[f], err_msg=f)
 
 
+def _worker_failing_rank(rank, world, out_dir, mode):
+    """mode "fault": the pass (iteration 1, colour 0) of rank 1 reports a capacity failure (MVS_FAULT_PASS);
+    mode "pool": rank 1's pool has room for the seeds only (mvs_config.max_patches), rank 0's the default capacity."""
+    import time
+
+    sys.path.insert(0, ROOT)
+    os.environ["MVS_CCL_LIBRARY"] = LOOPBACK_LIB
+    if mode == "fault":
+        os.environ["MVS_FAULT_PASS"] = "1:1:0"
+    from mvskit_amd import engine
+
+    sc, seeds = _scene()
+    kw = dict(max_patches=int(seeds.shape[0])) if (mode == "pool" and rank == 1) else {}
+    e = engine.Engine(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=5, device=0, shard_index=rank, shard_count=world, **kw)
+    e.set_scene(sc)
+    e.upload_patches(seeds)
+    uid_path = os.path.join(out_dir, "uid.bin")
+    if rank == 0:
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(e.comm_unique_id())
+        os.replace(uid_path + ".tmp", uid_path)
+    t0 = time.time()
+    while not os.path.exists(uid_path):
+        assert time.time() - t0 < 120
+        time.sleep(0.05)
+    with open(uid_path, "rb") as f:
+        e.comm_init(f.read(), rank, world)
+    log = []
+    for it in range(ITERS):
+        try:
+            c = e.propagate(it)
+            log.append((it, 0, c["patches"]))
+        except engine.EngineError as err:
+            log.append((it, err.status, 0))
+            if mode == "fault":  # the pass was given up on every rank alike: the same iteration runs again and goes through
+                c = e.propagate(it)
+                log.append((it, 0, c["patches"]))
+            else:
+                break
+        e.update_threshold()
+    np.save(os.path.join(out_dir, f"fail_log_{rank}.npy"), np.array(log, dtype=np.int64))
+    np.save(os.path.join(out_dir, f"fail_pool_{rank}.npy"), e.patches().view(np.uint8))
+    e.comm_release()
+
+
+@pytest.mark.parametrize("mode", ["fault", "pool"])
+def test_rank_local_failure_is_agreed_by_all_ranks(tmp_path, mode):
+    """A failure on ONE rank -- its pass overflowed, or its pool is smaller than the other ranks' -- reaches every rank through
+    the status word / the minimum headroom of mvs_engine_exchange's all-gather: all ranks return the same MVS_ERR_CAPACITY
+    from the same mvs_engine_propagate, none is left waiting in a collective (the workers would run into the loopback's
+    barrier time-out and the spawn would fail), and all hold identical pools afterwards."""
+    import subprocess
+
+    from mvskit_amd import engine
+
+    subprocess.check_call(["make", "-C", LOOPBACK_DIR, "-s"])
+    mp.spawn(_worker_failing_rank, args=(2, str(tmp_path), mode), nprocs=2, join=True)
+    logs = [np.load(tmp_path / f"fail_log_{r}.npy") for r in range(2)]
+    pools = [np.load(tmp_path / f"fail_pool_{r}.npy").view(engine.PATCH_DTYPE).reshape(-1) for r in range(2)]
+    np.testing.assert_array_equal(logs[0][:, :2], logs[1][:, :2])  # the same statuses in the same iterations on both ranks
+    failed = logs[0][logs[0][:, 1] != 0]
+    assert failed.shape[0] == 1 and failed[0, 1] == -4, logs[0]    # MVS_ERR_CAPACITY, once
+    assert failed[0, 0] == (1 if mode == "fault" else 0)
+    assert pools[0].tobytes() == pools[1].tobytes()
+    if mode == "fault":
+        assert logs[0][-1, 0] == ITERS - 1 and logs[0][-1, 1] == 0  # the run went on to the end
+        assert pools[0].shape[0] > _scene()[1].shape[0]
+
+
 def _worker_host_mirror(rank, world, out_dir):
     """One rank of the C++ host mirror: PmMvps::setRanks(rank, world, id file) -> init -> run (Propagate::run + Filter::run per
     iteration), the engine exchanging inside Propagate::run; the collective library is the loopback (ranks share the GPU)."""

@@ -420,6 +420,50 @@ def test_filter_run_matches_oracle(small_multi_scene):
         e.update_threshold()
 
 
+def _dense_pool(sc, per_cell, window=12, ref=0):
+    """`per_cell` patches in every cell of a `window` x `window` block of view `ref`'s grid (make_seeds' noisy plane seeds, one
+    draw per RNG seed), scored and scaled by hand: what Filter::run meets after a few iterations without the trim."""
+    recs = []
+    for k in range(per_cell):
+        sd = synth.make_seeds(sc, stride=1, seed=100 + k, views=[ref])
+        P = sc.P.astype(np.float64)[ref]
+        x = sd["coord"].astype(np.float64) @ P.T
+        cx = np.floor(x[:, 0] / x[:, 2] + 0.5).astype(int) // 2
+        cy = np.floor(x[:, 1] / x[:, 2] + 0.5).astype(int) // 2
+        keep = (cx >= 60) & (cx < 60 + window) & (cy >= 50) & (cy < 50 + window)
+        recs.append(sd[keep])
+    pool = np.ascontiguousarray(np.concatenate(recs))
+    pool["ncc"] = 0.9
+    pool["dscale"] = 0.004
+    return pool
+
+
+def test_filter_neighbor_dense_cells_take_the_retry_launch(small_plane_scene):
+    """Filter::filterNeighbor on cells that hold 30 patches each: a patch meets ~750 others in its 5x5 cells, more neighbours than the
+    first launch's row buffer holds (576), so it goes to the second launch (16384-slot id set, 64 KB of LDS) -- the path the
+    reference's unbounded findNeighbors (patch_manager.cpp:671-728) needs and no other test reaches.  Removal counts, lists and the
+    surviving patches equal the oracle's, whose table-size rule is the same."""
+    sc = small_plane_scene
+    pool = _dense_pool(sc, per_cell=30)
+    assert pool.shape[0] > 4000
+    o, e = _pair(sc, seed=3, enable_check=1, minImageNum=2)
+    o.add_patches(pool)
+    e.upload_patches(pool)
+    o.update_threshold()
+    e.update_threshold()  # m_depth 2: isVisible tests depths
+    fo, fe = o.filter(), e.filter()
+    st = e.filter_stats()
+    assert st["neighbor_retried"] > 1000, st
+    assert fo == fe, (fo, fe)
+    po, pe = o.patches(), e.patches()
+    assert po.shape == pe.shape and pe.shape[0] > 1000
+    np.testing.assert_array_equal(po["images"], pe["images"])
+    np.testing.assert_array_equal(po["vimages"], pe["vimages"])
+    np.testing.assert_array_equal(po["coord"], pe["coord"])
+    o.close()
+    e.close()
+
+
 RANDOM_CASES = [  # (nviews, W, H, arc, kind, level, csize, wsize, minImageNum, masks, view_propagation, stride, max_propag)
     (3, 200, 150, 25.0, "plane", 0, 2, 7, 2, False, 0, 4, 2),
     (4, 224, 160, 40.0, "multi", 0, 1, 5, 2, True, 0, 6, 2),
