@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--filter", action="store_true", help="BASELINE config 5: run Filter::run (filter.cpp:25-49) after every iteration, inside the timed region")
     ap.add_argument("--no-config5", dest="config5", action="store_false", help="skip the extra repetition with Filter::run that fills the `config5` block")
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal: run the N>1 code path (RCCL exchange) with a world of 1")
+    ap.add_argument("--list-cap", type=int, default=0, help="views per m_images / m_vimages list = which engine library (16, 32, 64); 0 = the smallest that holds --views")
     ap.add_argument("--scene-cache", default=os.path.join("/tmp", "mvskit_scene_cache"))
     return ap.parse_args()
 
@@ -127,7 +128,8 @@ def cpu_baseline(args, sc, seeds, pool_after_iter0, gpu_patches_by_iter):
     import oracle_binding as ob
 
     half = max(1.0, args.cpu_seconds / 2)
-    kw = dict(level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_FAITHFUL, sum_mode=ob.SUM_SEQ, refine_steps=args.refine_steps, seed=1)
+    kw = dict(level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_FAITHFUL, sum_mode=ob.SUM_SEQ, refine_steps=args.refine_steps, seed=1,
+              list_cap=args.list_cap, wide=args.list_cap > 32)
     samples = []
     for name, it, recs, check in (("A", 0, seeds, 0), ("B", 1, pool_after_iter0, 1)):
         if recs is None:
@@ -159,7 +161,7 @@ def cpu_baseline(args, sc, seeds, pool_after_iter0, gpu_patches_by_iter):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, int(os.environ.get("MVS_CPU_THREADS", "16"))))  # a one-GPU box's CPU share is 16 cores
     o = ob.Oracle(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64,
-                  enable_check=0, refine_steps=args.refine_steps, seed=1, nthreads=cores)
+                  enable_check=0, refine_steps=args.refine_steps, seed=1, nthreads=cores, list_cap=args.list_cap, wide=args.list_cap > 32)
     o.set_scene(sc)
     o.add_patches(seeds)
     o.set_time_budget(max(1.0, args.cpu_seconds / 3))
@@ -225,8 +227,9 @@ def main():
     if rank != 0:
         sc, seeds = load_scene(args, rank)
 
-    e = eng.Engine(args.views, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=1, refine_steps=args.refine_steps,
+    e = eng.Engine(args.views, list_cap=args.list_cap or None, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=1, refine_steps=args.refine_steps,
                    shard_index=rank, shard_count=world, device=dev_index, nccThreshold=NCC0, depth=DEPTH0)
+    args.list_cap = e.list_cap
     if rank == 0:
         log(f"scene ready: {sc.nviews} views {sc.W}x{sc.H}, {seeds.shape[0]} seeds; world {world}" + (" (ranks share a GPU: host-staged exchange over gloo)" if shared_gpu else ""))
     torch.cuda.synchronize()
@@ -373,7 +376,7 @@ def main():
                                    f"1 seed per {args.seed_stride}x{args.seed_stride} cells per view; the 3-iteration schedule of PmMvps::run (nccThreshold 0.70/0.65/0.60, "
                                    f"m_depth 1/2/3, Optim::check from m_depth 2) run {reps} time(s)" + (f" + its first {extra} iteration(s)" if extra else "")
                                    + f" = {args.steps} timed steps after {args.warmup} warm-up step(s); pool and thresholds reset between repetitions outside the timed region",
-                       "views": args.views, "width": args.width, "height": args.height, "csize": 2, "wsize": 7, "iterations_per_repetition": SCHEDULE_ITERS,
+                       "views": args.views, "width": args.width, "height": args.height, "csize": 2, "wsize": 7, "list_cap": args.list_cap, "iterations_per_repetition": SCHEDULE_ITERS,
                        "repetitions": reps, "extra_iterations": extra, "refine_evals": 1 + 4 * args.refine_steps, "check_depth2": True, "filter_run": bool(args.filter),
                        "parallelism": "single GPU" if world == 1 else f"the (view, cell) sequence sharded in {world} contiguous ranges over {world} ranks; per colour pass: {exchange}"},
             "patches": patches,

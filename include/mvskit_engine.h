@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define MVS_MAX_IMAGES 32 /* storage of Patch::m_images / m_vimages in a record */
+#ifndef MVS_MAX_IMAGES
+#define MVS_MAX_IMAGES 32 /* storage of Patch::m_images / m_vimages in a record; 64 for libmvskit_engine_cap64.so (compile callers with -DMVS_MAX_IMAGES=64) */
+#endif
 #define MVS_LIST_CAP 16   /* lists are truncated to this many views in the default build; see mvs_list_cap() */
 
 typedef enum mvs_status {
@@ -38,7 +40,7 @@ typedef enum mvs_status {
     MVS_ERR_NO_DEVICE = -5
 } mvs_status;
 
-/* Patch record: pmmvps/patch.hpp:33-66.  coord.w = 1, normal.w = 0.  128 bytes. */
+/* Patch record: pmmvps/patch.hpp:33-66.  coord.w = 1, normal.w = 0.  128 bytes (192 with MVS_MAX_IMAGES 64: mvs_patch_bytes()). */
 typedef struct mvs_patch {
     float coord[4];   /* Patch::m_coord */
     float normal[4];  /* Patch::m_normal */
@@ -113,6 +115,7 @@ int mvs_device_count(void);
  * libmvskit_engine_cap32.so (the same sources built with -DMVS_LISTCAP=32: twice the setRefImage LDS, 2 waves per SIMD),
  * which is the library to load for data sets of more than 16 views. */
 int mvs_list_cap(void);
+int mvs_patch_bytes(void); /* sizeof(mvs_patch) in this build of the library: 128, or 192 in libmvskit_engine_cap64.so -- a caller checks it against its own */
 void mvs_default_config(mvs_config* cfg); /* Option::Option, option.cpp:19-33 */
 
 /* PmMvps::init (pmmvps.cpp:18-68): thresholds, tau = min(2*minImageNum, nviews), maxLevel = level+3 */
@@ -215,6 +218,8 @@ typedef struct mvs_timing {
     int32_t sweep_launches;
     float exchange_ms;      /* mvs_engine_exchange: count all-gather + record / kill-id broadcasts (HIP events) */
     int64_t exchange_bytes; /* bytes this rank received in them */
+    int64_t check_retried_cells; /* destination cells whose Optim::check met more patches than the wave's LDS id set holds and that ran
+                                  * again on the second tier (a 16384-slot set in global memory); normally 0 */
 } mvs_timing;
 int mvs_engine_last_timing(mvs_engine* e, mvs_timing* t);
 

@@ -10,6 +10,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmvskit_engine.so")
 LIB32_PATH = os.path.join(LIB_DIR, "libmvskit_engine_cap32.so")  # the same sources with 32-view lists (-DMVS_LISTCAP=32)
+LIB64_PATH = os.path.join(LIB_DIR, "libmvskit_engine_cap64.so")  # 64-view lists and 192-byte records (-DMVS_LISTCAP=64 -DMVS_MAX_IMAGES=64)
+ENGINE_LIBS = {16: LIB_PATH, 32: LIB32_PATH, 64: LIB64_PATH}
+CAP_FLAGS = {16: [], 32: ["-DMVS_LISTCAP=32"], 64: ["-DMVS_LISTCAP=64", "-DMVS_MAX_IMAGES=64"]}
 SOURCES = ["mvs_kernels.hip", "mvs_engine.cpp"]
 DEPS = SOURCES + ["mvs_device.cuh", "mvs_check.cuh", "mvs_types.h", "mvs_kernels.h", os.path.join(ROOT, "include", "mvskit_engine.h")]
 
@@ -34,13 +37,15 @@ def needs_build(path: str = LIB_PATH) -> bool:
     return False
 
 
-def build_engine(force: bool = False, verbose: bool = False, cap32: bool = False) -> str:
-    out = LIB32_PATH if cap32 else LIB_PATH
+def build_engine(force: bool = False, verbose: bool = False, cap32: bool = False, cap: int = 0) -> str:
+    """cap: 16 (default), 32 or 64 views per m_images / m_vimages list (cap32=True is cap=32)."""
+    cap = cap or (32 if cap32 else 16)
+    out = ENGINE_LIBS[cap]
     if not force and not needs_build(out):
         return out
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + (["-DMVS_LISTCAP=32"] if cap32 else []) + os.environ.get("MVS_EXTRA_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + CAP_FLAGS[cap] + os.environ.get("MVS_EXTRA_FLAGS", "").split()
     cmd += ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out, "-ldl"]
     if verbose:
@@ -52,13 +57,17 @@ def build_engine(force: bool = False, verbose: bool = False, cap32: bool = False
 HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libmvskit_host.so")
 HOST_LIB32_PATH = os.path.join(LIB_DIR, "libmvskit_host_cap32.so")
+HOST_LIB64_PATH = os.path.join(LIB_DIR, "libmvskit_host_cap64.so")
+HOST_LIBS = {16: HOST_LIB_PATH, 32: HOST_LIB32_PATH, 64: HOST_LIB64_PATH}
 
 
-def build_host(force: bool = False, verbose: bool = False, cap32: bool = False) -> str:
+def build_host(force: bool = False, verbose: bool = False, cap32: bool = False, cap: int = 0) -> str:
     """The host-side mirror of the reference classes (C++, g++), linked against the engine's C ABI -- one host library per
-    engine build: libmvskit_host.so -> libmvskit_engine.so (view lists of 16), libmvskit_host_cap32.so -> the 32-view build."""
-    out = HOST_LIB32_PATH if cap32 else HOST_LIB_PATH
-    eng = LIB32_PATH if cap32 else LIB_PATH
+    engine build: libmvskit_host.so -> libmvskit_engine.so (view lists of 16), libmvskit_host_cap32.so -> the 32-view build,
+    libmvskit_host_cap64.so -> the 64-view build (192-byte records: -DMVS_MAX_IMAGES=64)."""
+    cap = cap or (32 if cap32 else 16)
+    out = HOST_LIBS[cap]
+    eng = ENGINE_LIBS[cap]
     srcs = [os.path.join(HOST_DIR, "pmmvps_host.cpp"), os.path.join(HOST_DIR, "jpeg_decode.cpp"), os.path.join(HOST_DIR, "ply_read.cpp")]
     deps = srcs + [os.path.join(HOST_DIR, "pmmvps_host.hpp"), os.path.join(HOST_DIR, "jpeg_decode.hpp"), os.path.join(HOST_DIR, "ply_read.hpp"),
                    os.path.join(ROOT, "include", "mvskit_engine.h"), eng]
@@ -66,8 +75,8 @@ def build_host(force: bool = False, verbose: bool = False, cap32: bool = False) 
         return out
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), *srcs, "-o", out,
-           "-L", LIB_DIR, "-l" + os.path.basename(eng)[3:-3], "-Wl,-rpath,$ORIGIN"]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] + (["-DMVS_MAX_IMAGES=64"] if cap == 64 else [])
+    cmd += ["-I", os.path.join(ROOT, "include"), *srcs, "-o", out, "-L", LIB_DIR, "-l" + os.path.basename(eng)[3:-3], "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -75,7 +84,6 @@ def build_host(force: bool = False, verbose: bool = False, cap32: bool = False) 
 
 
 if __name__ == "__main__":
-    print(build_engine(force=True, verbose=True))
-    print(build_engine(force=True, verbose=True, cap32=True))
-    print(build_host(force=True, verbose=True))
-    print(build_host(force=True, verbose=True, cap32=True))
+    for c in (16, 32, 64):
+        print(build_engine(force=True, verbose=True, cap=c))
+        print(build_host(force=True, verbose=True, cap=c))

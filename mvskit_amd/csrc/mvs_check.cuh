@@ -47,6 +47,7 @@ struct CheckCtx {
     const int* live_ids;    // LDS: the destination cell's current list
     unsigned long long* st; // diagnostic build (-DMVS_STAGE_TIMING): DCounters::stage, else unused
 };
+#define MVS_BIG_SLOTS 256   // global-memory id sets of Optim::check's second tier: one per block of k_sweep_retry
 #ifdef MVS_STAGE_TIMING
 #define CK_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
 #define CK_ADD(k) { const unsigned long long t1_ = CK_NOW(); if (cx.st) cx.st[k] += t1_ - ck_t; ck_t = t1_; }
@@ -180,6 +181,20 @@ DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
 //   phase B: the table is streamed 64 slots at a time: record gather (next chunk's loads in flight), predicate,
 //            ballot compaction of the accepted ids to the front of the table.
 #define MVS_SET_EMPTY (-1)
+// The id set and the rows normally live in LDS (G = false: plain accesses).  G = true is the second tier of Optim::check inside
+// the sweep (k_sweep_retry): a neighbourhood that does not fit the wave's LDS gets a 16384-slot table in GLOBAL memory
+// (SweepArgs::big_tables, one per block).  There every access is an agent-scope atomic load / store, i.e. served by L2: the
+// table's atomicMax updates happen in L2, and a plain load could still find a line in this CU's vector cache from an earlier use.
+template <bool G> DEV int tb_ld(const int* t, int i) {
+    if (G) return __hip_atomic_load(t + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t[i];
+}
+template <bool G> DEV void tb_st(int* t, int i, int v) {
+    if (G) __hip_atomic_store(t + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else t[i] = v;
+}
+template <bool G> DEV float tb_ldf(const float* t, int i) { return __int_as_float(tb_ld<G>(reinterpret_cast<const int*>(t), i)); }
+template <bool G> DEV void tb_stf(float* t, int i, float v) { tb_st<G>(reinterpret_cast<int*>(t), i, __float_as_int(v)); }
 // home slot of an id: multiplicative (Fibonacci) hashing, the top log2(capacity) bits of id * 2^32 / phi -- one multiply and
 // a shift per list entry instead of the avalanche of mix32 (ids are dense small integers; the oracle's set_home is the same)
 template <int HCAP> DEV unsigned set_home(int k) {
@@ -196,7 +211,7 @@ DEV bool set_insert_from(int* table, unsigned mask, int k, unsigned p) {
     }
     return false;
 }
-template <int HCAP>
+template <int HCAP, bool G = false>
 DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin,
                        unsigned* stats = nullptr) {
     const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
@@ -226,7 +241,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     const float thr = prm.neighborThreshold * scale;
     CK_BEGIN()
     __syncthreads();
-    for (int t = wc.lane; t < HCAP; t += 64) table[t] = MVS_SET_EMPTY;
+    for (int t = wc.lane; t < HCAP; t += 64) tb_st<G>(table, t, MVS_SET_EMPTY);
     __syncthreads();
     // ---- phase A
     const int side = 2 * margin + 1, per = side * side;
@@ -282,28 +297,28 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     for (int k = 0; k < HCAP / 64; k += 4) {  // four chunks of 64 slots per step: their reads are in flight together
         int v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = table[(k + u) * 64 + wc.lane];
+        for (int u = 0; u < 4; ++u) v[u] = tb_ld<G>(table, (k + u) * 64 + wc.lane);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const unsigned long long m = ballot(v[u] >= 0);
-            if (v[u] >= 0) table[visited + __popcll(m & ((1ull << wc.lane) - 1ull))] = v[u];  // visited + rank <= 64 (k + u) + lane: already read
+            if (v[u] >= 0) tb_st<G>(table, visited + __popcll(m & ((1ull << wc.lane) - 1ull)), v[u]);  // visited + rank <= 64 (k + u) + lane: already read
             visited += (int)__popcll(m);
         }
     }
     __syncthreads();
     int count = 0;
-    int v_next = wc.lane < visited ? table[wc.lane] : -1;
+    int v_next = wc.lane < visited ? tb_ld<G>(table, wc.lane) : -1;
     PGeo g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));  // lanes past the end read record 0: harmless, unused
     for (int b0 = 0; b0 < visited; b0 += 64) {
         const int v_cur = v_next;
         const PGeo g_cur = g_next;
         if (b0 + 64 < visited) {
-            v_next = b0 + 64 + wc.lane < visited ? table[b0 + 64 + wc.lane] : -1;
+            v_next = b0 + 64 + wc.lane < visited ? tb_ld<G>(table, b0 + 64 + wc.lane) : -1;
             g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));
         }
         const bool acc = v_cur >= 0 && is_neighbor_radius(prm, me, g_cur, unit, thr, radius);
         const unsigned long long m = ballot(acc);
-        if (acc) table[count + __popcll(m & ((1ull << wc.lane) - 1ull))] = v_cur;  // count + rank <= b0 + lane: already read
+        if (acc) tb_st<G>(table, count + __popcll(m & ((1ull << wc.lane) - 1ull)), v_cur);  // count + rank <= b0 + lane: already read
         count += (int)__popcll(m);
     }
     __syncthreads();
@@ -367,16 +382,17 @@ DEV double shfl_f64(double x, int src) {
 // Filter::filterQuad, filter.cpp:329-392.  nb = sorted ids in LDS (n of them); rows = LDS scratch of 3*n floats
 // (fx, fy, fz per neighbour).  The three sums over the neighbours (mean distance, normal equations, residual) are
 // lane-strided partial sums (lane l takes neighbours l, l+64, ...) followed by a wave butterfly.
-DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, const int* nb, int n, float* rows) {
+template <bool G = false>
+DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, const int* nb, int n, float* rows, double* sums_lds = nullptr) {
     F4 xdir, ydir;
     ortho(c.normal, xdir, ydir);
     // one pass over the neighbours' records: the distance for the mean h, and the three projections of the offset, which wait
     // in the rows for the division by h
     float hp = 0.0f;
     for (int t = wc.lane; t < n; t += 64) {
-        const F4 diff = sub4(ld4(patch_ptr(prm, cx, nb[t])->coord), c.coord);
+        const F4 diff = sub4(ld4(patch_ptr(prm, cx, tb_ld<G>(nb, t))->coord), c.coord);
         hp += norm4(diff);
-        rows[3 * t + 0] = dot4(diff, xdir); rows[3 * t + 1] = dot4(diff, ydir); rows[3 * t + 2] = dot4(diff, c.normal);
+        tb_stf<G>(rows, 3 * t + 0, dot4(diff, xdir)); tb_stf<G>(rows, 3 * t + 1, dot4(diff, ydir)); tb_stf<G>(rows, 3 * t + 2, dot4(diff, c.normal));
     }
     float h = wave_sum(hp);
     h /= (float)n;
@@ -385,8 +401,8 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
 #pragma unroll
     for (int k = 0; k < 20; ++k) acc[k] = 0.0;
     for (int t = wc.lane; t < n; t += 64) {  // each lane reads back what it wrote
-        const float fx = rows[3 * t + 0] / h, fy = rows[3 * t + 1] / h, fz = rows[3 * t + 2];
-        rows[3 * t + 0] = fx; rows[3 * t + 1] = fy;
+        const float fx = tb_ldf<G>(rows, 3 * t + 0) / h, fy = tb_ldf<G>(rows, 3 * t + 1) / h, fz = tb_ldf<G>(rows, 3 * t + 2);
+        tb_stf<G>(rows, 3 * t + 0, fx); tb_stf<G>(rows, 3 * t + 1, fy);
         const float a[6] = {fx * fx, fy * fy, fx * fy, fx, fy, fz};
         int k = 0;
 #pragma unroll
@@ -401,7 +417,7 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
     // pivoted elimination of Filter::lls runs with one matrix element per lane -- the same operations in the same order as
     // the oracle's solve5 (every element update is f = M[r][col] / M[col][col]; M[r][k] -= f * M[col][k]), but 2 VGPRs of
     // matrix instead of 60 uniform registers.
-    double* sums = reinterpret_cast<double*>(rows + 3 * ((n + 1) & ~1));  // behind the rows, 8-byte aligned
+    double* sums = sums_lds ? sums_lds : reinterpret_cast<double*>(rows + 3 * ((n + 1) & ~1));  // behind the rows, 8-byte aligned (always LDS)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 20; ++k) {
@@ -474,7 +490,7 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
     }
     float rp = 0.0f;
     for (int t = wc.lane; t < n; t += 64) {
-        const float fx = rows[3 * t], fy = rows[3 * t + 1], fz = rows[3 * t + 2];
+        const float fx = tb_ldf<G>(rows, 3 * t), fy = tb_ldf<G>(rows, 3 * t + 1), fz = tb_ldf<G>(rows, 3 * t + 2);
         const float res = x0 * (fx * fx) + x1 * (fy * fy) + x2 * (fx * fy) + x3 * fx + x4 * fy - fz;
         rp += fabsf(res) / unit;
     }
@@ -493,7 +509,15 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
 #endif
 // Optim::check, optim.cpp:300-323.  lds: MVS_CHECK_LDS_FLOATS floats (the kernel's dynamic LDS region).
 // Returns 1 when the patch is rejected.  Neighbours beyond MVS_ROW_CAP are ignored (and flagged in *overflow).
-MVS_CHECK_FN int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, Cand& c, float* lds, int* overflow) {
+// Optim::check, optim.cpp:300-323.  lds: MVS_CHECK_LDS_FLOATS floats (the kernel's dynamic LDS region).
+// Returns 1 when the patch is rejected, 0 when it passes, and -1 when its 5x5-cell neighbourhood does not fit the wave's LDS id
+// set / row buffer (more than 7/8 of MVS_HASH_CAP distinct patches met, or more than MVS_ROW_CAP neighbours) and BIG is false:
+// the reference's findNeighbors (patch_manager.cpp:671-728) is unbounded, so the caller hands the whole destination cell to
+// the second tier.  BIG = true IS that second tier (k_sweep_retry; rare, exact, slow): the search runs again on a
+// MVS_FILTER2_HASH_CAP-slot table in global memory (`big_table`: the size Filter::filterNeighbor's second launch uses -- the
+// oracle's table-size rule is "the small set if it fits, else 16384"), filterQuad keeps its rows there and its 20 sums in LDS.
+template <bool BIG = false>
+MVS_CHECK_FN int check_patch(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, Cand& c, float* lds, int* overflow, int* big_table = nullptr) {
 #ifndef MVS_CHECK_STAGES
 #define MVS_CHECK_STAGES 3  // timing experiments only: 1 = gain, 2 = + neighbours, 3 = everything
 #endif
@@ -505,10 +529,15 @@ MVS_CHECK_FN int check_patch(const DParams& prm, const WaveCtx& wc, const CheckC
     if (MVS_CHECK_STAGES < 2) return 0;
     int* table = reinterpret_cast<int*>(lds);
     int n = find_neighbors<MVS_HASH_CAP>(prm, wc, cx, c, table, 4.0f, 2);
-    if (n < 0) { n = 0; if (wc.lane == 0) atomicOr(overflow, 4); }
+    if (n < 0 || n > MVS_ROW_CAP) {
+        if (!BIG) return -1;
+        n = find_neighbors<MVS_FILTER2_HASH_CAP, true>(prm, wc, cx, c, big_table, 4.0f, 2);
+        if (n < 0 || n > MVS_FILTER2_ROW_CAP) { if (wc.lane == 0) atomicOr(overflow, 4); return 0; }  // the engine's limit
+        if (6 < n && filter_quad<true>(prm, wc, cx, c, big_table, n, reinterpret_cast<float*>(big_table) + rows_offset(n), reinterpret_cast<double*>(lds))) { c.nimg = 0; return 1; }
+        return 0;
+    }
     if (MVS_CHECK_STAGES < 3) return 0;
     if (6 < n) {
-        if (n > MVS_ROW_CAP) { n = MVS_ROW_CAP; if (wc.lane == 0) atomicOr(overflow, 4); }
         CK_BEGIN()
         const int fq = filter_quad(prm, wc, cx, c, table, n, lds + rows_offset(n));
         CK_ADD(11)

@@ -42,6 +42,17 @@ DEV int rli(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
 DEV float rlf(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 DEV int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 DEV unsigned long long ballot(bool p) { return __ballot(p); }
+// one bit per entry of a view list: 32 bits serve the 16- and 32-view builds, the 64-view build needs all 64 lanes
+#if MVS_LISTCAP > 32
+typedef unsigned long long vmask_t;
+DEV int vpop(vmask_t m) { return __popcll(m); }
+#define MVS_VBITS 64
+#else
+typedef unsigned vmask_t;
+DEV int vpop(vmask_t m) { return __popc(m); }
+#define MVS_VBITS 32
+#endif
+DEV vmask_t vballot(bool p) { return (vmask_t)__ballot(p); }
 
 DEV float dot4(F4 a, F4 b) { return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x))); }
 DEV float dot3(F3 a, F3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
@@ -581,12 +592,12 @@ DEV void cls_raw(const ClsPend& p, unsigned cs, float& r, float& g, float& b) { 
 #define MVS_EV_PREFETCH 1
 #endif
 template <bool PIV = false>
-DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsigned (&okm)[1], float& incc_l, float* piv = nullptr,
+DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmask_t (&okm)[1], float& incc_l, float* piv = nullptr,
                     float* texs = nullptr, int tstride = 0, float* ssd_out = nullptr) {
     const ClsConst& cc = wc.cc;
     frames_publish(wc, f, MVS_LISTCAP > 16 ? MVS_LISTCAP : 16);
-    okm[0] = (unsigned)(ballot(f.ok != 0) & 0xffffffffull);  // a frame is only ever valid on a lane < n
-    wc.view_evals += (okm[0] & 1u) ? (unsigned)__popc(okm[0]) : 0u;
+    okm[0] = vballot(f.ok != 0);  // a frame is only ever valid on a lane < n <= MVS_LISTCAP
+    wc.view_evals += (okm[0] & 1u) ? (unsigned)vpop(okm[0]) : 0u;
     const int row = wc.lane >> 4, lc = wc.lane & 15;
     // the extra sample of view k in frame lane k (raw colours): its loads go out first, the first round's behind them
     float fxr = 0.0f, fxg = 0.0f, fxb = 0.0f;
@@ -681,9 +692,9 @@ DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, unsi
     incc_l = bperm_f(src, incc_v);
     if (ssd_out) *ssd_out = bperm_f(src, ssd_l);
     if (PIV) {
-        const bool okk = (okm[0] >> (wc.lane & 31)) & 1u;
+        const bool okk = (okm[0] >> (wc.lane & (MVS_VBITS - 1))) & 1u;
         const float a0 = bperm_f(src, mr_l), a1 = bperm_f(src, mg_l), a2 = bperm_f(src, mb_l);
-        piv[0] = (wc.lane < 32 && okk) ? a0 : 128.0f; piv[1] = (wc.lane < 32 && okk) ? a1 : 128.0f; piv[2] = (wc.lane < 32 && okk) ? a2 : 128.0f;
+        piv[0] = (wc.lane < MVS_VBITS && okk) ? a0 : 128.0f; piv[1] = (wc.lane < MVS_VBITS && okk) ? a1 : 128.0f; piv[2] = (wc.lane < MVS_VBITS && okk) ? a2 : 128.0f;
     }
 }
 
@@ -727,7 +738,7 @@ DEV float compute_incc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int
     const int sz = min(prm.tau, n);
     wc.evals++;
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < sz);
-    unsigned okm[1];
+    vmask_t okm[1];
     float incc_l;
     eval_views(prm, wc, f, sz, okm, incc_l);
     if (!(okm[0] & 1u)) return 2.0f;
@@ -743,7 +754,7 @@ DEV float compute_incc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int
     return score / total;
 }
 // tail of Optim::computeINCC (optim.cpp:690-705) on per-view robust INCCs that are already known
-DEV float weighted_incc(const DParams& prm, unsigned okm, float val_l, float weights, int n) {
+DEV float weighted_incc(const DParams& prm, vmask_t okm, float val_l, float weights, int n) {
     if (n < 2 || !(okm & 1u)) return 2.0f;
     const int sz = min(prm.tau, n);
     float score = 0.0f, total = 0.0f;
@@ -763,20 +774,20 @@ DEV float compute_ncc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int 
 }
 
 // Optim::setINCCs (vector), optim.cpp:708-746: returns the view-lane INCC array (reference vs every view)
-DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n, int robust, unsigned* okm_out = nullptr,
+DEV float set_inccs(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n, int robust, vmask_t* okm_out = nullptr,
                     float* texs = nullptr, int tstride = 0, float* ssd_out = nullptr) {
     const int ref = rli(img, 0);
     F4 px, py;
     get_paxes(prm, prm.views + ref, coord, normal, px, py);
     wc.evals++;
     const Frame f = make_frame(prm, coord, px, py, normal, img, wc.lane < n);
-    unsigned okm[1];
+    vmask_t okm[1];
     float incc_l;
     eval_views(prm, wc, f, n, okm, incc_l, nullptr, texs, tstride, ssd_out);
     if (okm_out) *okm_out = okm[0];
     if (!(okm[0] & 1u)) return 2.0f;
     float incc = robust ? robustincc(incc_l) : incc_l;
-    if (wc.lane >= MVS_LISTCAP || !((okm[0] >> (wc.lane & 31)) & 1u)) incc = 2.0f;
+    if (wc.lane >= MVS_LISTCAP || !((okm[0] >> (wc.lane & (MVS_VBITS - 1))) & 1u)) incc = 2.0f;
     if (wc.lane == 0) incc = 0.0f;
     return incc;
 }
@@ -828,12 +839,12 @@ DEV void add_images(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c
 struct KeptTex {
     float* texs; int tstride;
     float ssd;       // view lanes (old index)
-    unsigned okm;    // bit k: old view k sampled
+    vmask_t okm;     // bit k: old view k sampled
     int orig;        // view lanes (current index) -> old index
 };
 DEV void constraint_images(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c, float nccThreshold, float keep_w = 0.0f, int keep_n = 0,
                            KeptTex* kt = nullptr) {
-    unsigned okm = 0u;
+    vmask_t okm = 0u;
     float ssd = 1.0f;
     const float inccs = set_inccs(prm, wc, c.coord, c.normal, c.img, c.nimg, 0, &okm, kt ? kt->texs : nullptr, kt ? kt->tstride : 0, kt ? &ssd : nullptr);
     if (keep_n > 0) c.ncc = 1.0f - unrobustincc(weighted_incc(prm, okm, robustincc(inccs), keep_w, keep_n));
@@ -1029,11 +1040,11 @@ DEV void cost_func4(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
         for (int j = 0; j < 4; ++j) fv[j] = ((okm[j] & 1u) && d[j] >= minimum - 1) ? rld(q, j) : 2.0;
     } else {
         wc.evals += 1;
-        unsigned okm[1];
+        vmask_t okm[1];
         if (piv) eval_views<true>(prm, wc, f, sz, okm, incc_l, piv);  // refinePatch's first evaluation: the view means become the pivots
         else eval_views(prm, wc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
-        fv[0] = cost_of_group(prm, wc, okm[0], val_l, 0, sz, minimum);
+        fv[0] = cost_of_group(prm, wc, (unsigned)okm[0], val_l, 0, sz, minimum);  // sz <= tau <= 16 views
     }
 }
 // Optim::refinePatch, optim.cpp:480-547, BOBYQA replaced by the halving random search
@@ -1121,14 +1132,14 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     const int n = c.nimg;
     const int ref = rli(c.img, 0);
     WC_T0(wc)
-    unsigned okmask = 0;
+    vmask_t okmask = 0;
     float ssd_l = 1.0f;
     int orig = wc.lane;  // where view i's texture lies
     if (kt) {
         texs = kt->texs;
         orig = wc.lane < n ? kt->orig : 0;
         ssd_l = __shfl(kt->ssd, orig);
-        okmask = (unsigned)ballot(wc.lane < n && ((kt->okm >> orig) & 1u));
+        okmask = vballot(wc.lane < n && ((kt->okm >> orig) & 1u));
         __syncthreads();
     } else {
     F4 px, py;
@@ -1138,11 +1149,11 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     WC_ADD(wc, 1)
     // centred textures to LDS behind the frames this evaluation publishes, their ssd to view lanes
     texs += MVS_FRAME1_LDS_BYTES / 4;
-    unsigned okm1[1];
+    vmask_t okm1[1];
     float incc_unused;
     eval_views(prm, wc, f, n, okm1, incc_unused, nullptr, texs, tstride, &ssd_l);
     okmask = okm1[0];
-    if (!(okmask & 1u)) wc.view_evals += (unsigned)__popc(okmask);  // Optim::setINCCs (matrix) samples every view, whatever the first one did
+    if (!(okmask & 1u)) wc.view_evals += (unsigned)vpop(okmask);  // Optim::setINCCs (matrix) samples every view, whatever the first one did
     }
     const float inv_l = inv_msd(prm, ssd_l);
     WC_ADD(wc, 2)
@@ -1150,7 +1161,11 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     // one lane per pair (a, b), a < b < n: 120 pairs = 2 rounds of 64 lanes for 16 views (496 = 8 rounds for 32); the
     // robust INCC of pair q goes to LDS behind the textures
     const int npairs = n * (n - 1) / 2;
+#if MVS_LISTCAP > 32
+    float* pairv = texs + prm.list_n * 3 * tstride;   // behind the textures (the 64-view build sizes its LDS by the data set's view count)
+#else
     float* pairv = texs + MVS_LISTCAP * 3 * tstride;  // behind the textures
+#endif
     for (int r = 0; r * 64 < npairs; ++r) {
         const int q0 = wc.lane + 64 * r;
         int q = q0;

@@ -18,7 +18,7 @@
 #include "mvs_types.h"
 
 static_assert(sizeof(mvs_patch) == sizeof(DPatch), "mvs_patch and DPatch must be the same bytes");
-static_assert((MVS_LISTCAP == 16 || MVS_LISTCAP == 32) && MVS_LISTCAP <= MVS_MAXI && MVS_MAX_IMAGES == MVS_MAXI, "limits out of sync");
+static_assert((MVS_LISTCAP == 16 || MVS_LISTCAP == 32 || MVS_LISTCAP == 64) && MVS_LISTCAP <= MVS_MAXI && MVS_MAX_IMAGES == MVS_MAXI, "limits out of sync");
 
 namespace {
 thread_local std::string g_err;
@@ -154,6 +154,9 @@ struct mvs_engine {
     DevBuf<unsigned long long> misc;  // [0] stage_counter, [1..2] fill_ncc evals, [3] trimmed
     DevBuf<DCounters> counters;
     DevBuf<int32_t> error_flag;
+    DevBuf<int32_t> big_tables, retry_jobs;  // Optim::check's second tier (k_sweep_retry): 256 id sets of 16384 ints, the cells to run again
+    int64_t retried_cells = 0;               // destination cells that went to the second tier since the engine was created
+    int64_t pass_retried = 0;                // ... in the last pass
     SweepArgs sa{};
     bool staged = false;      // a pass has run and was not committed yet
     bool counted = false;     // commit_count + scans done for the staged pass
@@ -213,6 +216,7 @@ void derive_params(mvs_engine* e) {  // PmMvps::init, pmmvps.cpp:32-36,54-67
     p.inv_3sz = 1.0f / (float)(3 * c.wsize * c.wsize);
     p.neighborThreshold = 0.5f; p.neighborThreshold1 = 1.0f;
     p.quadThreshold = c.quadThreshold;
+    p.list_n = std::min<int>(MVS_LISTCAP, c.nviews);
 }
 
 void invert3(const float* P, float* Minv) {  // Matrix3f::inverse (camera.cpp:304,335), in double
@@ -298,11 +302,18 @@ int build_list(mvs_engine* e, bool vgrid, bool trim) {
     DevBuf<int32_t>& id32 = vgrid ? e->vid32 : e->id32;
     DevBuf<int32_t>& cnt_alive = vgrid ? e->vcnt_alive : e->cnt_alive;
     HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
-    mvsk_index_count(p, vgrid ? nullptr : cnt.p, vgrid ? cnt.p : nullptr, st);
+    HIPCHK(hipMemsetAsync(e->misc.p + 6, 0, sizeof(unsigned long long), st));
+    mvsk_index_count(p, vgrid ? nullptr : cnt.p, vgrid ? cnt.p : nullptr, e->misc.p + 6, st);
     mvsk_exclusive_scan(cnt.p, start.p, nc, e->scan_tmp.p, st);
     int32_t tot = 0;
+    unsigned long long tot64 = 0;
     HIPCHK(hipMemcpyAsync(&tot, start.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&tot64, e->misc.p + 6, sizeof tot64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (tot64 > (unsigned long long)(INT32_MAX - 64)) {  // every patch sits in the cell list of each of its views: offsets are 32-bit
+        g_err = "cell index: more than 2^31 list entries (patches x views per patch); lower mvs_config.max_patches";
+        return MVS_ERR_CAPACITY;
+    }
     if (int r = ids.ensure(tot + 16)) return r;
     if (int r = fat.ensure(tot + 16)) return r;
     if (int r = id32.ensure(tot + 16)) return r;
@@ -427,6 +438,7 @@ extern "C" {
 const char* mvs_last_error(void) { return g_err.c_str(); }
 
 int mvs_list_cap(void) { return MVS_LISTCAP; }
+int mvs_patch_bytes(void) { return (int)sizeof(mvs_patch); }
 
 int mvs_device_count(void) {
     int n = 0;
@@ -482,6 +494,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     e->vcursor.release(); e->vids.release(); e->fat.release(); e->vfat.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
+    e->big_tables.release(); e->retry_jobs.release();
     e->tmp_rec_in.release(); e->tmp_rec_out.release(); e->tmp_f_in.release(); e->tmp_f_out.release(); e->tmp_i.release(); e->tmp_bytes.release();
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->fev) if (ev) (void)hipEventDestroy(ev);
@@ -770,11 +783,25 @@ static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     a.kill = e->kill.p;
     a.counters = e->counters.p;
     a.error_flag = e->error_flag.p;
+    if (want_vgrid(e)) {  // Optim::check runs in this pass: its second tier needs its global-memory tables and the list of cells
+        if (int r = e->big_tables.ensure((int64_t)256 * 16384)) return r;
+        if (int r = e->retry_jobs.ensure(std::max<int64_t>(nj, 16))) return r;
+    }
+    a.big_tables = e->big_tables.p; a.retry_jobs = e->retry_jobs.p; a.nretry = reinterpret_cast<int32_t*>(e->misc.p + 5);
+    HIPCHK(hipMemsetAsync(e->misc.p + 5, 0, sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(e->misc.p, 0, sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(e->counters.p, 0, sizeof(DCounters), st));
     HIPCHK(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
     const DParams p = current_params(e);
     mvsk_sweep(p, a, st);
+    e->pass_retried = 0;
+    if (want_vgrid(e)) {  // cells whose Optim::check outgrew the wave's LDS run again on the second tier (normally none)
+        int32_t nretry = 0;
+        HIPCHK(hipMemcpyAsync(&nretry, a.nretry, sizeof nretry, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        e->pass_retried = nretry;
+        if (nretry > 0) { mvsk_sweep_retry(p, a, nretry, st); e->retried_cells += nretry; }
+    }
     HIPCHK(hipEventRecord(e->ev[2], st));
     DCounters hc;
     int32_t herr = 0;
@@ -788,6 +815,7 @@ static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->timing.index_ms = ms;
     (void)hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->timing.sweep_ms = ms;
     e->timing.commit_ms = 0.0f; e->timing.sweep_launches = 1; e->timing.exchange_ms = 0.0f; e->timing.exchange_bytes = 0;
+    e->timing.check_retried_cells = e->pass_retried;
     e->staged = true; e->counted = false;
     if (out) {
         out->candidates = (int64_t)hc.candidates; out->prefiltered = (int64_t)hc.prefiltered; out->patches = (int64_t)hc.patches;
@@ -817,8 +845,7 @@ static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     }
     if (herr & 3) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
     if (herr & 4) {
-        g_err = MVS_LISTCAP > 16 ? "mvs_engine_pass: Optim::check met more than 3584 patches around one patch, or more than 1152 neighbours (engine limit)"
-                                 : "mvs_engine_pass: Optim::check met more than 1792 patches around one patch, or more than 576 neighbours (engine limit)";
+        g_err = "mvs_engine_pass: Optim::check met more than 14336 patches around one patch, or more than 4064 neighbours (engine limit)";
         return MVS_ERR_CAPACITY;
     }
     return MVS_OK;
@@ -1043,7 +1070,7 @@ int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out) {  // Propa
         }
         add_counters(total, c);
         tt.index_ms += e->timing.index_ms; tt.sweep_ms += e->timing.sweep_ms; tt.commit_ms += e->timing.commit_ms; tt.sweep_launches += 1;
-        tt.exchange_ms += e->timing.exchange_ms; tt.exchange_bytes += e->timing.exchange_bytes;
+        tt.exchange_ms += e->timing.exchange_ms; tt.exchange_bytes += e->timing.exchange_bytes; tt.check_retried_cells += e->timing.check_retried_cells;
     }
     e->timing = tt;
     if (out) *out = total;

@@ -9,7 +9,7 @@ void mvsk_pyr_down(const uint32_t* src, int pw, int ph, uint32_t* dst, int w, in
 void mvsk_mask_down(const uint8_t* src, int pw, int ph, uint8_t* dst, int w, int h, hipStream_t st);
 void mvsk_mask_binarise(uint8_t* m, int64_t n, hipStream_t st);
 void mvsk_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, hipStream_t st);
-void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, hipStream_t st);
+void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, unsigned long long* total, hipStream_t st);
 void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, unsigned long long* ids, const int32_t* vstart, int32_t* vcursor, unsigned long long* vids, hipStream_t st);
 void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st);
 void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* id32, int32_t* cnt_alive, hipStream_t st);
@@ -19,6 +19,7 @@ void mvsk_map_extract(const DParams& prm, int view, int kind, const unsigned lon
 void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st);
 size_t mvsk_sweep_lds_bytes(const DParams& prm);
 void mvsk_sweep(const DParams& prm, const SweepArgs& a, hipStream_t st);
+void mvsk_sweep_retry(const DParams& prm, const SweepArgs& a, int nretry, hipStream_t st);
 void mvsk_job_work(const DParams& prm, const SweepArgs& a, int mode, int shift, int32_t* work, hipStream_t st);
 void mvsk_job_cuts(const int32_t* scan, int64_t njobs, int n, int32_t* cuts, hipStream_t st);
 void mvsk_commit_count(const SweepArgs& a, int32_t* cnt, hipStream_t st);

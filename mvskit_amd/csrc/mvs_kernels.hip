@@ -1,5 +1,6 @@
 // mvs_kernels.hip -- HIP kernels of the MI355X PatchMatch-MVS engine (gfx950, wave64).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "mvs_device.cuh"
 #include "mvs_check.cuh"
 #include "mvs_kernels.h"
@@ -103,30 +104,35 @@ __device__ __forceinline__ unsigned long long list_key(float ncc, int64_t id) {
 }
 // =================================================================== index build
 // cnt[gcell] += 1 for every (patch, view) membership: PatchManager::addPatch, patch_manager.cpp:158-186
-__global__ void k_index_count(DParams prm, int32_t* __restrict__ cnt, int32_t* __restrict__ vcnt) {
+__global__ void k_index_count(DParams prm, int32_t* __restrict__ cnt, int32_t* __restrict__ vcnt, unsigned long long* __restrict__ total) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= prm.pool_n) return;
-    const DPatch* p = prm.pool + id;
-    if (!(p->flags & 1)) return;
-    const F4 coord = ld4(p->coord);
-    const int n = cnt ? min(p->nimages, MVS_LISTCAP) : 0;
-    for (int i = 0; i < n; ++i) {
-        const DView* vw = prm.views + p->images[i];
-        int ix, iy;
-        cell_of(prm, vw, coord, ix, iy);
-        if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
-        atomicAdd(&cnt[vw->cell_base + iy * vw->gw + ix], 1);
-    }
-    if (vcnt) {
-        const int nv = min(p->nvimages, MVS_LISTCAP);
-        for (int i = 0; i < nv; ++i) {
-            const DView* vw = prm.views + p->vimages[i];
+    int mine = 0;  // list entries this patch adds: their sum must stay below 2^31 (the index offsets are 32-bit)
+    if (id < prm.pool_n && (prm.pool[id].flags & 1)) {
+        const DPatch* p = prm.pool + id;
+        const F4 coord = ld4(p->coord);
+        const int n = cnt ? min(p->nimages, MVS_LISTCAP) : 0;
+        for (int i = 0; i < n; ++i) {
+            const DView* vw = prm.views + p->images[i];
             int ix, iy;
             cell_of(prm, vw, coord, ix, iy);
             if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
-            atomicAdd(&vcnt[vw->cell_base + iy * vw->gw + ix], 1);
+            atomicAdd(&cnt[vw->cell_base + iy * vw->gw + ix], 1);
+            ++mine;
+        }
+        if (vcnt) {
+            const int nv = min(p->nvimages, MVS_LISTCAP);
+            for (int i = 0; i < nv; ++i) {
+                const DView* vw = prm.views + p->vimages[i];
+                int ix, iy;
+                cell_of(prm, vw, coord, ix, iy);
+                if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
+                atomicAdd(&vcnt[vw->cell_base + iy * vw->gw + ix], 1);
+                ++mine;
+            }
         }
     }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, (unsigned long long)mine);
 }
 __global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int32_t* __restrict__ cursor, unsigned long long* __restrict__ ids,
                              const int32_t* __restrict__ vstart, int32_t* __restrict__ vcursor, unsigned long long* __restrict__ vids) {
@@ -355,34 +361,28 @@ __global__ void k_job_cuts(const int32_t* __restrict__ scan, int64_t njobs, int 
 #ifndef MVS_SWEEP_WAVES
 #define MVS_SWEEP_WAVES 3  // waves per SIMD the register allocator is asked to fit: 168 VGPRs (4 waves = 128 VGPRs spills ~110 of them; measured 19.4 vs 18.9 M patches/s)
 #endif
-__global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, SweepArgs a) {
-    __shared__ int s_scratch[192];
-    extern __shared__ float s_texs[];
-    // XCD-aware job order: blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8).
+// BIG = false: the sweep proper (k_sweep).  BIG = true: the second tier (k_sweep_retry) -- the few destination cells in which an
+// Optim::check met a neighbourhood larger than the wave's LDS id set run again, from the start, with a global-memory table for such
+// checks (mvs_check.cuh).  A cell of the first launch that meets such a check gives up: nothing it staged counts (job_nstage = 0)
+// and its counters are dropped.  The cells of a colour pass are independent of each other and a cell's run is deterministic (RNG
+// keyed by iteration, view, cell, source slot, trial), so the second run repeats the first up to the point where it gave up -- the
+// pool patches the first run evicted until then are exactly the first evictions of the second: their kill flags may stand.
 #ifdef MVS_STAGE_TIMING
 #define ST_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
 #define ST_ADD(k, t0) { const unsigned long long t1_ = ST_NOW(); st_acc[k] += t1_ - (t0); (t0) = t1_; }
-    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long st_begin = ST_NOW();
-    unsigned long long st_t = st_begin;
 #else
 #define ST_ADD(k, t0)
 #endif
 #ifndef MVS_XCD_CHUNK
 #define MVS_XCD_CHUNK 128
 #endif
-#if MVS_XCD_CHUNK > 0
-    // chunks of MVS_XCD_CHUNK consecutive jobs (a stretch of one grid row) go to one XCD, consecutive chunks to
-    // consecutive XCDs: the destination and its source cells share an L2, and every XCD gets the same mix of cheap and
-    // expensive regions.  (One contiguous band of cells per XCD left XCDs idle for a quarter of the launch: the bands
-    // -- one and a half views each -- differ in work; measured 770 -> 603 ms per iteration.)
-    const int64_t bi = blockIdx.x >> 3;
-    const int64_t job = a.job_lo + (bi / MVS_XCD_CHUNK) * (8 * MVS_XCD_CHUNK) + (int64_t)(blockIdx.x & 7u) * MVS_XCD_CHUNK + (bi % MVS_XCD_CHUNK);
-#else
-    const int64_t chunk = (a.job_hi - a.job_lo + 7) / 8;
-    const int64_t job = a.job_lo + (int64_t)(blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+template <bool BIG>
+DEV void sweep_cell(const DParams& prm, const SweepArgs& a, const int64_t job, int* s_scratch, float* s_texs, int* big_table) {
+#ifdef MVS_STAGE_TIMING
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = ST_NOW();
+    unsigned long long st_t = st_begin;
 #endif
-    if (job >= a.job_hi) return;
     int v, cx, cy;
     job_cell(prm, a, job, v, cx, cy);
     const DView* vw = prm.views + v;
@@ -416,6 +416,7 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
         if (wc.lane < L_n) { L_id = fe[wc.lane].id; L_ncc = fe[wc.lane].ncc; }
     }
     int ns = 0;  // staged records of this job
+    bool gave_up = false;
     const float icx = (float)(prm.csize * (2 * cx + 1) - 1) / 2.0f, icy = (float)(prm.csize * (2 * cy + 1) - 1) / 2.0f;
 
     // sources: the cell above/below, the cell beside (propagate.cpp:104-108), and -- view propagation, the branch the
@@ -480,8 +481,9 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
 #else
                     const CheckCtx cx{a.staging, v, cell, L_n, s_scratch, nullptr};
 #endif
-                    const int chk_r = check_patch(prm, wc, cx, c, s_texs, a.error_flag);
+                    const int chk_r = check_patch<BIG>(prm, wc, cx, c, s_texs, a.error_flag, big_table);
                     ST_ADD(5, st_t)
+                    if (!BIG && chk_r < 0) { gave_up = true; break; }  // the neighbourhood does not fit LDS: this cell goes to k_sweep_retry
                     if (chk_r) { ++n_f1; continue; }
                 }
                 // staging slot for the accepted patch
@@ -516,7 +518,13 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
                 }
                 ST_ADD(6, st_t)
             }
+            if (gave_up) break;
         }
+        if (gave_up) break;
+    }
+    if (!BIG && gave_up) {
+        if (wc.lane == 0) { a.job_nstage[job] = 0; a.retry_jobs[atomicAdd(a.nretry, 1)] = (int32_t)job; }
+        return;
     }
     if (wc.lane == 0) {
         a.job_nstage[job] = ns;
@@ -536,6 +544,35 @@ __global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, Swee
         atomicMax(&C->stage[12], st_acc[12]); atomicMax(&C->stage[13], st_acc[13]);
         atomicAdd(&C->stage[14], wc.st_acc[3]); atomicAdd(&C->stage[15], wc.st_acc[4]);  // inside postProcess: setRefImage's pair sums and choice
 #endif
+    }
+}
+
+__global__ __launch_bounds__(64, MVS_SWEEP_WAVES) void k_sweep(DParams prm, SweepArgs a) {
+    __shared__ int s_scratch[192];
+    extern __shared__ float s_texs[];
+    // XCD-aware job order: blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8).
+#if MVS_XCD_CHUNK > 0
+    // chunks of MVS_XCD_CHUNK consecutive jobs (a stretch of one grid row) go to one XCD, consecutive chunks to
+    // consecutive XCDs: the destination and its source cells share an L2, and every XCD gets the same mix of cheap and
+    // expensive regions.  (One contiguous band of cells per XCD left XCDs idle for a quarter of the launch: the bands
+    // -- one and a half views each -- differ in work; measured 770 -> 603 ms per iteration.)
+    const int64_t bi = blockIdx.x >> 3;
+    const int64_t job = a.job_lo + (bi / MVS_XCD_CHUNK) * (8 * MVS_XCD_CHUNK) + (int64_t)(blockIdx.x & 7u) * MVS_XCD_CHUNK + (bi % MVS_XCD_CHUNK);
+#else
+    const int64_t chunk = (a.job_hi - a.job_lo + 7) / 8;
+    const int64_t job = a.job_lo + (int64_t)(blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+#endif
+    if (job >= a.job_hi) return;
+    sweep_cell<false>(prm, a, job, s_scratch, s_texs, nullptr);
+}
+// the second tier: block b runs the cells retry_jobs[b], retry_jobs[b + gridDim.x], ... with big_tables slot b
+__global__ __launch_bounds__(64, 1) void k_sweep_retry(DParams prm, SweepArgs a, int nretry) {
+    __shared__ int s_scratch[192];
+    extern __shared__ float s_texs[];
+    int* big_table = a.big_tables + (size_t)blockIdx.x * MVS_FILTER2_HASH_CAP;
+    for (int k = blockIdx.x; k < nretry; k += gridDim.x) {
+        __syncthreads();
+        sweep_cell<true>(prm, a, (int64_t)a.retry_jobs[k], s_scratch, s_texs, big_table);
     }
 }
 
@@ -563,7 +600,7 @@ __global__ void k_commit_copy(SweepArgs a, const int32_t* __restrict__ base, DPa
         if (o >= dst_cap) { atomicOr(a.error_flag, 2); return; }
         const uint4* s4 = reinterpret_cast<const uint4*>(sp);
         uint4* d4 = reinterpret_cast<uint4*>(dst + o);
-        for (int w = 0; w < 8; ++w) d4[w] = s4[w];
+        for (int w = 0; w < (int)MVS_REC_U4; ++w) d4[w] = s4[w];
         if (per_view) atomicAdd(&per_view[(sp->flags >> 8) & 0xff], 1);
         if (!keep_key) { dst[o].flags = 1; dst[o].id = 0; }
     }
@@ -589,7 +626,7 @@ __global__ void k_append_records(DPatch* pool, int64_t pool_n, const DPatch* __r
     if (i >= n) return;
     const uint4* s4 = reinterpret_cast<const uint4*>(recs + i);
     uint4* d4 = reinterpret_cast<uint4*>(pool + pool_n + i);
-    for (int w = 0; w < 8; ++w) d4[w] = s4[w];
+    for (int w = 0; w < (int)MVS_REC_U4; ++w) d4[w] = s4[w];
     pool[pool_n + i].flags = 1;
     pool[pool_n + i].id = 0;
 }
@@ -602,7 +639,7 @@ __global__ void k_alive_gather(const DPatch* __restrict__ pool, int64_t n, const
     if (i >= n || !(pool[i].flags & 1) || base[i] >= cap) return;
     const uint4* s4 = reinterpret_cast<const uint4*>(pool + i);
     uint4* d4 = reinterpret_cast<uint4*>(out + base[i]);
-    for (int w = 0; w < 8; ++w) d4[w] = s4[w];
+    for (int w = 0; w < (int)MVS_REC_U4; ++w) d4[w] = s4[w];
     out[base[i]].id = (int32_t)i;
 }
 
@@ -652,7 +689,7 @@ __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kil
 // loaded together, then the five patches they name, then the five tests run on one ray / unit / factor -- two dependent
 // gathers per lane instead of ten, at four times the lanes per instruction of the one-patch-per-wave form.
 // Then, patch by patch: the surviving views in ascending order and Optim::setRefImage with the whole wave.
-#define MVS_FE_LANES (MVS_LISTCAP <= 16 ? 16 : 32)  // lanes per patch in the visibility phase
+#define MVS_FE_LANES (MVS_LISTCAP <= 16 ? 16 : (MVS_LISTCAP <= 32 ? 32 : 64))  // lanes per patch in the visibility phase
 #define MVS_FE_PATCHES (64 / MVS_FE_LANES)
 __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage) {
     __shared__ int s_scratch[192];
@@ -712,11 +749,11 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
     const unsigned long long alive_b = ballot(alive_l);
     const int tstride = prm.wsz;  // odd for 7x7 / 5x5 windows: the lane-per-pair reads of setRefImage fall in distinct banks
     for (int g = 0; g < MVS_FE_PATCHES; ++g) {
-        if (!((alive_b >> (MVS_FE_LANES * g)) & 1ull)) continue;
+        if (!((alive_b >> ((MVS_FE_LANES * g) & 63)) & 1ull)) continue;
         DPatch* p = prm.pool + ((int64_t)blockIdx.x * MVS_FE_PATCHES + g);
         Cand c;
         load_cand(p, wc, c);
-        const unsigned sm = (unsigned)((safe_b >> (MVS_FE_LANES * g)) & ((1ull << MVS_FE_LANES) - 1ull));  // bit i: view m_images[i] of patch g survives
+        const vmask_t sm = (vmask_t)((safe_b >> ((MVS_FE_LANES * g) & 63)) & (MVS_FE_LANES == 64 ? ~0ull : (1ull << (MVS_FE_LANES & 63)) - 1ull));  // bit i: view m_images[i] of patch g survives
         // the survivors in ascending view order (the image-major loop of filterExactSub)
         __syncthreads();
         if (wc.lane < MVS_MAXVIEWS) s_scratch[wc.lane] = 0;
@@ -879,8 +916,10 @@ __global__ __launch_bounds__(64) void k_probe(DParams prm, int op, int64_t n, co
     } else if (op == 3) {
         int f = post_process(prm, wc, s_scratch, s_texs, tstride, c);
         if (f == 0 && prm.depth >= 2 && prm.enable_check) {
-            const CheckCtx cx{in, -1, -1, 0, s_scratch};  // no staged ids in a probe (a null pointer here crashes clang 22)
-            if (check_patch(prm, wc, cx, c, s_texs, out_i + n)) f = -1;  // out_i[n]: overflow flag word
+            const CheckCtx cx{in, -1, -1, 0, s_scratch, nullptr};  // no staged ids in a probe (a null pointer here crashes clang 22)
+            const int chk = check_patch(prm, wc, cx, c, s_texs, out_i + n);  // out_i[n]: overflow flag word
+            if (chk < 0) { if (wc.lane == 0) atomicOr(out_i + n, 4); }       // no second tier in a probe
+            else if (chk) f = -1;
         }
         store_cand(out + i, wc, c, 1, (int)i);
         if (wc.lane == 0) out_i[i] = f;
@@ -921,8 +960,8 @@ void mvsk_mask_down(const uint8_t* src, int pw, int ph, uint8_t* dst, int w, int
 }
 void mvsk_mask_binarise(uint8_t* m, int64_t n, hipStream_t st) { hipLaunchKernelGGL(k_mask_binarise, dim3(nblk(n, 256)), dim3(256), 0, st, m, n); }
 void mvsk_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, hipStream_t st) { launch_exclusive_scan(in, out, n, tmp, st); }
-void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, cnt, vcnt);
+void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, unsigned long long* total, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, cnt, vcnt, total);
 }
 void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, unsigned long long* ids, const int32_t* vstart, int32_t* vcursor, unsigned long long* vids, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, start, cursor, ids, vstart, vcursor, vids);
@@ -949,7 +988,12 @@ void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st
 size_t mvsk_sweep_lds_bytes(const DParams& prm) {
     // setRefImage: the centred textures of MVS_LISTCAP views (9408 B at wsize 7 and 16 views) + one value per view pair
     // in postProcess they lie behind the frame region (the evaluation that produces them publishes its frames there)
-    const size_t texs = MVS_FRAME1_LDS_BYTES + ((size_t)MVS_LISTCAP * 3 * prm.wsz + (size_t)MVS_LISTCAP * (MVS_LISTCAP - 1) / 2) * sizeof(float);
+#if MVS_LISTCAP > 32
+    const size_t ln = (size_t)prm.list_n;  // the 64-view build: no list is longer than the data set has views
+#else
+    const size_t ln = MVS_LISTCAP;
+#endif
+    const size_t texs = MVS_FRAME1_LDS_BYTES + (ln * 3 * prm.wsz + ln * (ln - 1) / 2) * sizeof(float);
     const size_t chk = (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float);                      // Optim::check hash set + rows
     const size_t need = texs > chk ? texs : chk;
     return need > (size_t)MVS_FRAME_LDS_BYTES ? need : (size_t)MVS_FRAME_LDS_BYTES;  // the frames + pivots of a refinement step
@@ -972,6 +1016,10 @@ void mvsk_job_work(const DParams& prm, const SweepArgs& a, int mode, int shift, 
 }
 void mvsk_job_cuts(const int32_t* scan, int64_t njobs, int n, int32_t* cuts, hipStream_t st) {
     if (njobs > 0) hipLaunchKernelGGL(k_job_cuts, dim3(nblk(njobs, 256)), dim3(256), 0, st, scan, njobs, n, cuts);
+}
+void mvsk_sweep_retry(const DParams& prm, const SweepArgs& a, int nretry, hipStream_t st) {
+    if (nretry <= 0) return;
+    hipLaunchKernelGGL(k_sweep_retry, dim3((unsigned)std::min(nretry, MVS_BIG_SLOTS)), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, a, nretry);
 }
 void mvsk_commit_count(const SweepArgs& a, int32_t* cnt, hipStream_t st) { hipLaunchKernelGGL(k_commit_count, dim3(nblk(a.njobs, 256)), dim3(256), 0, st, a, cnt); }
 void mvsk_commit_copy(const SweepArgs& a, const int32_t* base, DPatch* dst, int64_t dst_cap, int32_t* per_view, int keep_key, hipStream_t st) {

@@ -7,7 +7,11 @@
 #ifndef MVS_LISTCAP
 #define MVS_LISTCAP 16     // m_images / m_vimages are truncated to 16 views
 #endif
+#if MVS_LISTCAP > 32
+#define MVS_MAXI 64        // the 64-view build (libmvskit_engine_cap64.so): records of 192 bytes, no list is ever cut (nviews <= 64)
+#else
 #define MVS_MAXI 32        // storage in the record
+#endif
 #define MVS_MAXVIEWS 64    // one lane per view in the per-view phases
 #define MVS_CAPMAX 32      // MAX_NUM_OF_PATCHES = max_propag * csize^2 <= 32
 #define MVS_NEWBASE 0x40000000  // ids >= NEWBASE: staged record NEWBASE + slot
@@ -21,7 +25,8 @@ struct DPatch {
     uint8_t images[MVS_MAXI];
     uint8_t vimages[MVS_MAXI];
 };
-static_assert(sizeof(DPatch) == 128, "record is 128 bytes");
+static_assert(sizeof(DPatch) == 64 + 2 * MVS_MAXI, "record is 128 bytes (192 in the 64-view build)");
+#define MVS_REC_U4 (sizeof(DPatch) / 16)  // a record as 16-byte words
 
 // Entry of a cell list in the per-pass index: the patch id plus the fields the list consumers need (sort key,
 // reference view, and the geometry of PmMvps::isNeighbor*), so that walking a list is one contiguous stream
@@ -65,6 +70,7 @@ struct DParams {
     float sortThreshold, ascaleConst, neighborThreshold, neighborThreshold1, quadThreshold;
     float inv_sz, inv_3sz;  // 1/wsize^2 and 1/(3 wsize^2)
     int32_t total_cells;
+    int32_t list_n;         // min(MVS_LISTCAP, nviews): no list is longer; sizes the kept textures of setRefImage in the 64-view build
     const DView* views;
     DPatch* pool;
     int64_t pool_n;
@@ -107,4 +113,7 @@ struct SweepArgs {
     uint8_t* kill;        // [pool_cap]
     DCounters* counters;
     int32_t* error_flag;
+    int32_t* big_tables;  // Optim::check's second tier (k_sweep_retry): 16384-slot id sets in global memory, one per block
+    int32_t* retry_jobs;  // the destination cells (jobs) the first launch handed to the second tier, and
+    int32_t* nretry;      //   how many
 };

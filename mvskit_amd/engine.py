@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 from . import build
-from .synth import MAX_IMAGES, PATCH_DTYPE  # noqa: F401  (PATCH_DTYPE mirrors mvs_patch)
+from . import synth
+from .synth import MAX_IMAGES, PATCH_DTYPE  # noqa: F401  (PATCH_DTYPE mirrors mvs_patch at 32 list slots)
 
 PROBE_NCC, PROBE_PREPROCESS, PROBE_REFINE, PROBE_POSTPROCESS, PROBE_COST, PROBE_MATH = range(6)
 
@@ -22,7 +23,7 @@ EXPORTS = [
     "mvs_engine_pass", "mvs_engine_export_counts", "mvs_engine_export_device", "mvs_engine_commit_device",
     "mvs_engine_commit_local", "mvs_engine_depth_normal_map", "mvs_engine_probe", "mvs_engine_last_timing",
     "mvs_engine_filter", "mvs_comm_unique_id", "mvs_engine_comm_init", "mvs_engine_comm_attach", "mvs_engine_comm_release",
-    "mvs_engine_exchange", "mvs_list_cap", "mvs_engine_filter_stats",
+    "mvs_engine_exchange", "mvs_list_cap", "mvs_engine_filter_stats", "mvs_patch_bytes",
 ]
 
 
@@ -51,7 +52,7 @@ class Counters(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("index_ms", C.c_float), ("sweep_ms", C.c_float), ("commit_ms", C.c_float), ("sweep_launches", C.c_int32),
-                ("exchange_ms", C.c_float), ("exchange_bytes", C.c_int64)]
+                ("exchange_ms", C.c_float), ("exchange_bytes", C.c_int64), ("check_retried_cells", C.c_int64)]
 
 
 class FilterStats(C.Structure):
@@ -71,11 +72,12 @@ class EngineError(RuntimeError):
 _libs = {}
 
 
-def load_library(cap32: bool = False):
-    """Loads libmvskit_engine.so -- or, for view lists of up to 32 entries, libmvskit_engine_cap32.so (the same sources
-    built with -DMVS_LISTCAP=32) -- built in-tree by mvskit_amd.build / __graft_entry__.build."""
-    default = build.LIB32_PATH if cap32 else build.LIB_PATH
-    LIB_PATH = os.environ.get("MVS_ENGINE_LIB32" if cap32 else "MVS_ENGINE_LIB", default)  # development: A/B timing of two builds on one box
+def load_library(cap32: bool = False, cap: int = 0):
+    """Loads libmvskit_engine.so (view lists of 16) -- or libmvskit_engine_cap32.so / _cap64.so, the same sources built with
+    -DMVS_LISTCAP=32 / 64 (the latter with 192-byte records) -- built in-tree by mvskit_amd.build / __graft_entry__.build."""
+    cap = cap or (32 if cap32 else 16)
+    default = build.ENGINE_LIBS[cap]
+    LIB_PATH = os.environ.get({16: "MVS_ENGINE_LIB", 32: "MVS_ENGINE_LIB32", 64: "MVS_ENGINE_LIB64"}[cap], default)  # development: A/B timing of two builds on one box
     if LIB_PATH in _libs:
         return _libs[LIB_PATH]
     if not os.path.exists(LIB_PATH):
@@ -119,6 +121,7 @@ def load_library(cap32: bool = False):
     L.mvs_engine_comm_release.argtypes = [vp]
     L.mvs_engine_exchange.argtypes = [vp]
     L.mvs_list_cap.restype = C.c_int
+    L.mvs_patch_bytes.restype = C.c_int
     L.mvs_engine_filter_stats.argtypes = [vp, C.POINTER(FilterStats)]
     _libs[LIB_PATH] = L
     return L
@@ -132,11 +135,13 @@ class Engine:
     """One PmMvps instance whose Propagate::run lives on an MI355X (pmmvps/pmmvps.cpp:76-114)."""
 
     def __init__(self, nviews, list_cap=None, **kw):
-        """list_cap: 16 or 32 views per m_images / m_vimages list (which library); default 16 up to 16 views, else 32."""
+        """list_cap: 16, 32 or 64 views per m_images / m_vimages list (which library); default: the smallest that holds `nviews`,
+        so that no list is ever cut short.  `dtype` is the record this library takes and returns (192 bytes at 64)."""
         if list_cap is None:
-            list_cap = 32 if nviews > 16 else 16
-        self.L = load_library(cap32=list_cap > 16)
+            list_cap = 16 if nviews <= 16 else (32 if nviews <= 32 else 64)
+        self.L = load_library(cap=list_cap)
         self.list_cap = self.L.mvs_list_cap()
+        self.dtype = synth.patch_dtype((self.L.mvs_patch_bytes() - 64) // 2)
         self.cfg = Config()
         self.L.mvs_default_config(C.byref(self.cfg))
         self.cfg.nviews = nviews
@@ -208,7 +213,7 @@ class Engine:
 
     # ---- patches
     def upload_patches(self, recs):
-        recs = np.ascontiguousarray(recs, dtype=PATCH_DTYPE)
+        recs = synth.convert_records(recs, self.dtype)
         self._check(self.L.mvs_engine_upload_patches(self.h, recs.shape[0], _ptr(recs)))
 
     add_patches = upload_patches
@@ -224,7 +229,7 @@ class Engine:
     def patches(self):
         n = C.c_int64()
         self._check(self.L.mvs_engine_download_patches(self.h, 0, None, C.byref(n)))
-        out = np.zeros(n.value, dtype=PATCH_DTYPE)
+        out = np.zeros(n.value, dtype=self.dtype)
         if n.value:
             self._check(self.L.mvs_engine_download_patches(self.h, n.value, _ptr(out), C.byref(n)))
         return out
@@ -288,7 +293,7 @@ class Engine:
         t = Timing()
         self._check(self.L.mvs_engine_last_timing(self.h, C.byref(t)))
         return {"index_ms": t.index_ms, "sweep_ms": t.sweep_ms, "commit_ms": t.commit_ms, "sweep_launches": t.sweep_launches,
-                "exchange_ms": t.exchange_ms, "exchange_bytes": int(t.exchange_bytes)}
+                "exchange_ms": t.exchange_ms, "exchange_bytes": int(t.exchange_bytes), "check_retried_cells": int(t.check_retried_cells)}
 
     def depth_normal_map(self, view, kind):
         gw, gh = self.grid_dims(view)
@@ -305,9 +310,9 @@ class Engine:
             out = np.zeros((x.shape[0], 5), np.float32)
             self._check(self.L.mvs_engine_probe(self.h, op, x.shape[0], None, _ptr(x), None, _ptr(out), None))
             return out
-        recs = np.ascontiguousarray(recs, dtype=PATCH_DTYPE)
+        recs = synth.convert_records(recs, self.dtype)
         n = recs.shape[0]
-        out_rec = np.zeros(n, dtype=PATCH_DTYPE)
+        out_rec = np.zeros(n, dtype=self.dtype)
         out_f = np.zeros(n, np.float32)
         out_i = np.zeros(n, np.int32)
         self._check(self.L.mvs_engine_probe(self.h, op, n, _ptr(recs), None, _ptr(out_rec), _ptr(out_f), _ptr(out_i)))

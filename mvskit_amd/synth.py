@@ -19,24 +19,47 @@ import numpy as np
 
 MAX_IMAGES = 32
 
-#: numpy mirror of `mvs_patch` (include/mvskit_engine.h) -- 128 bytes.
-PATCH_DTYPE = np.dtype(
-    [
-        ("coord", "<f4", (4,)),
-        ("normal", "<f4", (4,)),
-        ("ncc", "<f4"),
-        ("dscale", "<f4"),
-        ("ascale", "<f4"),
-        ("tmp", "<f4"),
-        ("nimages", "<i4"),
-        ("nvimages", "<i4"),
-        ("flags", "<i4"),
-        ("id", "<i4"),
-        ("images", "u1", (MAX_IMAGES,)),
-        ("vimages", "u1", (MAX_IMAGES,)),
-    ],
-    align=False,
-)
+def patch_dtype(max_images: int = MAX_IMAGES) -> np.dtype:
+    """numpy mirror of `mvs_patch` (include/mvskit_engine.h) with MVS_MAX_IMAGES = max_images: 128 bytes at 32, 192 bytes at 64
+    (libmvskit_engine_cap64.so)."""
+    return np.dtype(
+        [
+            ("coord", "<f4", (4,)),
+            ("normal", "<f4", (4,)),
+            ("ncc", "<f4"),
+            ("dscale", "<f4"),
+            ("ascale", "<f4"),
+            ("tmp", "<f4"),
+            ("nimages", "<i4"),
+            ("nvimages", "<i4"),
+            ("flags", "<i4"),
+            ("id", "<i4"),
+            ("images", "u1", (max_images,)),
+            ("vimages", "u1", (max_images,)),
+        ],
+        align=False,
+    )
+
+
+def convert_records(recs, dtype: np.dtype) -> np.ndarray:
+    """Patch records in another record width (32 <-> 64 list slots): scalar fields copied, lists copied as far as they fit."""
+    recs = np.asarray(recs)
+    if recs.dtype == dtype:
+        return np.ascontiguousarray(recs)
+    out = np.zeros(recs.shape[0], dtype=dtype)
+    for name in ("coord", "normal", "ncc", "dscale", "ascale", "tmp", "nimages", "nvimages", "flags", "id"):
+        out[name] = recs[name]
+    for name in ("images", "vimages"):
+        k = min(out[name].shape[1], recs[name].shape[1])
+        out[name][:, :k] = recs[name][:, :k]
+    cap = out["images"].shape[1]
+    out["nimages"] = np.minimum(out["nimages"], cap)
+    out["nvimages"] = np.minimum(out["nvimages"], cap)
+    return out
+
+
+#: the default record: 32 list slots, 128 bytes
+PATCH_DTYPE = patch_dtype(MAX_IMAGES)
 assert PATCH_DTYPE.itemsize == 128
 
 

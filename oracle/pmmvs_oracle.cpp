@@ -2140,6 +2140,7 @@ int orc_clear_patches(orc_scene* h) {
 }
 int64_t orc_list_truncations(orc_scene* h) { return h->s.list_truncations.load(); }
 int orc_list_storage(void) { return MAXI; }
+int orc_patch_bytes(void) { return (int)sizeof(orc_patch); }
 int orc_set_cell_budget(orc_scene* h, int64_t n) { h->s.cell_budget = n; return 0; }
 int orc_set_time_budget(orc_scene* h, double seconds) { h->s.time_budget = seconds; return 0; }
 double orc_last_sweep_seconds(orc_scene* h) { return h->s.last_sweep_seconds; }

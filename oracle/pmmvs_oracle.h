@@ -21,7 +21,11 @@
 extern "C" {
 #endif
 
+#ifdef ORC_WIDE_LISTS
+#define ORC_MAX_IMAGES 64 /* the wide build (make wide): 64 views per list, records of 192 bytes -- what the 64-view engine build is checked against */
+#else
 #define ORC_MAX_IMAGES 32 /* capacity of Patch::m_images / m_vimages in the restatement */
+#endif
 
 /* Patch record, follows pmmvps/patch.hpp:33-66 (coord w=1, normal w=0). */
 typedef struct orc_patch {
@@ -37,7 +41,7 @@ typedef struct orc_patch {
     int32_t id;       /* pool index */
     uint8_t images[ORC_MAX_IMAGES];  /* m_images, [0] = reference view */
     uint8_t vimages[ORC_MAX_IMAGES]; /* m_vimages */
-} orc_patch; /* 128 bytes */
+} orc_patch; /* 128 bytes (192 in the wide build: orc_patch_bytes()) */
 
 enum { ORC_SCHEDULE_FAITHFUL = 0, ORC_SCHEDULE_ENGINE = 1 };
 enum { ORC_SUM_SEQ = 0, ORC_SUM_TREE64 = 1 };
@@ -119,6 +123,7 @@ int orc_filter(orc_scene* s, int64_t* removed4);
 /* faithful schedule only: bound the work (for timing a sample). <=0 means unlimited. */
 int64_t orc_list_truncations(orc_scene* s); /* times a view list wanted to grow past list_cap since orc_create */
 int orc_list_storage(void);                 /* views a list can hold in this build: 32, or 64 in the wide build */
+int orc_patch_bytes(void);                  /* sizeof(orc_patch) in this build */
 int orc_set_cell_budget(orc_scene* s, int64_t max_source_cells);
 int orc_set_time_budget(orc_scene* s, double seconds);
 double orc_last_sweep_seconds(orc_scene* h); /* engine schedule: wall time of the last colour pass's parallel loop */

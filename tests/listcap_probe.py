@@ -1,5 +1,5 @@
-"""Run by tests/test_oracle_kat.py::test_list_cap_48_views in a process of its own (MVS_ORACLE_LIB selects the wide build of
-the oracle, which stores 64 views per list): the same 48-view scene once with the engine's 16-view list cap and once with
+"""Run by tests/test_oracle_kat.py::test_list_cap_48_views in a process of its own, on the wide build of the oracle (64 views per
+list, 192-byte records): the same 48-view scene once with the engine's 16-view list cap and once with
 lists as long as the reference makes them (optim.cpp:165-205 pushes every qualifying view), two iterations of
 PmMvps::run's loop with Optim::check.  Prints one JSON line: how often a list wanted to be longer than 16, the patch
 counts, and how far the depth / normal maps of the two runs are apart."""
@@ -18,9 +18,9 @@ from mvskit_amd import synth  # noqa: E402
 
 def _run(sc, seeds, cap):
     nviews = sc.nviews
-    o = ob.Oracle(nviews, level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64, enable_check=1,
+    o = ob.Oracle(nviews, wide=True, level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64, enable_check=1,
                   seed=6, nthreads=8, list_cap=cap)
-    assert ob.lib().orc_list_storage() >= cap, "needs the wide oracle build (make -C oracle wide)"
+    assert o.L.orc_list_storage() >= cap, "needs the wide oracle build (make -C oracle wide)"
     o.set_scene(sc)
     o.add_patches(seeds)
     patches = 0
@@ -29,7 +29,7 @@ def _run(sc, seeds, cap):
         o.update_threshold()
     maps = [o.depth_normal_map(v, kind) for v in range(0, nviews, 4) for kind in (0, 1)]
     p = o.patches()
-    r = dict(patches=patches, alive=int(p.shape[0]), trunc=int(ob.lib().orc_list_truncations(o.h)), maps=maps,
+    r = dict(patches=patches, alive=int(p.shape[0]), trunc=int(o.L.orc_list_truncations(o.h)), maps=maps,
              mean_nimages=float(p["nimages"].mean()), max_nimages=int(p["nimages"].max()))
     o.close()
     return r

@@ -11,6 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+WIDE_LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle_wide.so")  # 64 views per list, 192-byte records (make -C oracle wide)
 
 MAX_IMAGES = 32
 PATCH_DTYPE = np.dtype(
@@ -18,6 +19,28 @@ PATCH_DTYPE = np.dtype(
      ("tmp", "<f4"), ("nimages", "<i4"), ("nvimages", "<i4"), ("flags", "<i4"), ("id", "<i4"),
      ("images", "u1", (MAX_IMAGES,)), ("vimages", "u1", (MAX_IMAGES,))])
 assert PATCH_DTYPE.itemsize == 128
+WIDE_PATCH_DTYPE = np.dtype(
+    [("coord", "<f4", (4,)), ("normal", "<f4", (4,)), ("ncc", "<f4"), ("dscale", "<f4"), ("ascale", "<f4"),
+     ("tmp", "<f4"), ("nimages", "<i4"), ("nvimages", "<i4"), ("flags", "<i4"), ("id", "<i4"),
+     ("images", "u1", (64,)), ("vimages", "u1", (64,))])
+assert WIDE_PATCH_DTYPE.itemsize == 192
+
+
+def convert_records(recs, dtype):
+    """records in the other list width: scalar fields copied, lists as far as they fit"""
+    recs = np.asarray(recs)
+    if recs.dtype == dtype:
+        return np.ascontiguousarray(recs)
+    out = np.zeros(recs.shape[0], dtype=dtype)
+    for name in ("coord", "normal", "ncc", "dscale", "ascale", "tmp", "nimages", "nvimages", "flags", "id"):
+        out[name] = recs[name]
+    for name in ("images", "vimages"):
+        k = min(out[name].shape[1], recs[name].shape[1])
+        out[name][:, :k] = recs[name][:, :k]
+    cap = out["images"].shape[1]
+    out["nimages"] = np.minimum(out["nimages"], cap)
+    out["nvimages"] = np.minimum(out["nvimages"], cap)
+    return out
 
 SCHEDULE_FAITHFUL, SCHEDULE_ENGINE = 0, 1
 SUM_SEQ, SUM_TREE64 = 0, 1
@@ -49,16 +72,16 @@ def build(force=False):
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get("MVS_ORACLE_LIB", LIB_PATH)  # `make -C oracle asan-test` points this at the sanitizer build
-    if path == LIB_PATH and not os.path.exists(LIB_PATH):
-        build()
+def lib(wide=False):
+    """wide: the build with 64 views per list and 192-byte records (-DORC_WIDE_LISTS) -- what the 64-view engine is compared with"""
+    path = WIDE_LIB_PATH if wide else os.environ.get("MVS_ORACLE_LIB", LIB_PATH)  # `make -C oracle asan-test` points this at the sanitizer build
+    if path in _libs:
+        return _libs[path]
+    if path in (LIB_PATH, WIDE_LIB_PATH) and not os.path.exists(path):
+        build(force=True)
     L = C.CDLL(path)
     vp, f32p, u8p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
     L.orc_default_config.argtypes = [C.POINTER(Config)]
@@ -127,7 +150,8 @@ def lib():
     L.orc_compute_gain.argtypes = [vp, vp]
     L.orc_compute_gain.restype = C.c_float
     L.orc_check.argtypes = [vp, vp]
-    _lib = L
+    L.orc_patch_bytes.restype = C.c_int
+    _libs[path] = L
     return L
 
 
@@ -142,8 +166,9 @@ def f4(*v):
 class Oracle:
     """One PmMvps-like scene held by the oracle."""
 
-    def __init__(self, nviews, **kw):
-        L = lib()
+    def __init__(self, nviews, wide=False, **kw):
+        L = lib(wide)
+        self.dtype = WIDE_PATCH_DTYPE if L.orc_patch_bytes() == 192 else PATCH_DTYPE
         self.cfg = Config()
         L.orc_default_config(C.byref(self.cfg))
         self.cfg.nviews = nviews
@@ -211,7 +236,7 @@ class Oracle:
 
     # ---- patches
     def add_patches(self, recs):
-        recs = np.ascontiguousarray(recs, dtype=PATCH_DTYPE)
+        recs = convert_records(recs, self.dtype)
         if self.L.orc_add_patches(self.h, recs.shape[0], _ptr(recs)) != 0:
             raise RuntimeError(self.L.orc_last_error().decode())
 
@@ -220,7 +245,7 @@ class Oracle:
 
     def patches(self):
         n = self.num_patches()
-        out = np.zeros(n, dtype=PATCH_DTYPE)
+        out = np.zeros(n, dtype=self.dtype)
         got = self.L.orc_get_patches(self.h, n, _ptr(out))
         return out[:got]
 
@@ -257,7 +282,7 @@ class Oracle:
     def export_new(self):
         per_view = np.zeros(self.cfg.nviews, dtype=np.int32)
         n = self.L.orc_export_new(self.h, 0, None, _ptr(per_view))
-        out = np.zeros(n, dtype=PATCH_DTYPE)
+        out = np.zeros(n, dtype=self.dtype)
         self.L.orc_export_new(self.h, n, _ptr(out), _ptr(per_view))
         return out, per_view
 
@@ -268,7 +293,7 @@ class Oracle:
         return ids
 
     def commit(self, recs, kills):
-        recs = np.ascontiguousarray(recs, dtype=PATCH_DTYPE)
+        recs = convert_records(recs, self.dtype)
         kills = np.ascontiguousarray(kills, dtype=np.int32)
         self.L.orc_commit(self.h, recs.shape[0], _ptr(recs), kills.shape[0], _ptr(kills))
 
@@ -311,11 +336,8 @@ class Oracle:
                                   _ptr(out), int(normalize))
         return flag, out
 
-    @staticmethod
-    def _one(rec):
-        a = np.zeros(1, dtype=PATCH_DTYPE)
-        a[0] = rec
-        return a
+    def _one(self, rec):
+        return convert_records(np.array(rec).reshape(1), self.dtype).copy()  # a private copy: the probes write into it
 
     def compute_incc(self, rec, robust=1):
         a = self._one(rec)
@@ -327,7 +349,7 @@ class Oracle:
 
     def set_inccs(self, rec, robust=0):
         a = self._one(rec)
-        out = np.zeros(MAX_IMAGES, np.float32)
+        out = np.zeros(64, np.float32)
         n = self.L.orc_set_inccs(self.h, _ptr(a), robust, _ptr(out))
         return out[:n]
 
@@ -372,7 +394,7 @@ class Oracle:
 
     def generate_patch(self, src, icoord):
         a = self._one(src)
-        out = np.zeros(1, dtype=PATCH_DTYPE)
+        out = np.zeros(1, dtype=self.dtype)
         f = self.L.orc_generate_patch(self.h, _ptr(a), _ptr(f4(*icoord)), _ptr(out))
         return f, out[0].copy()
 

@@ -21,6 +21,8 @@ def _pair(scene, **kw):
     for k, v in kw.items():
         okw[k] = v
         ekw[k] = v
+    if okw.get("list_cap", 0) > 32:
+        okw["wide"] = True  # 64 views per list: the oracle's wide build (192-byte records, as libmvskit_engine_cap64.so)
     o = ob.Oracle(n, **okw)
     e = engine.Engine(n, **ekw)
     o.set_scene(scene)
@@ -321,25 +323,28 @@ def test_variant_min_image_num(min_image_num):
     assert c["patches"] > 200 and c["inserted"] > 50
 
 
-@pytest.mark.parametrize("list_cap", [32, 16])
+@pytest.mark.parametrize("list_cap", [64, 32, 16])
 def test_variant_48_views(list_cap):
-    # BASELINE.json configs[3] has 48 views: more views than a record stores (MVS_MAX_IMAGES 32) or lists keep, so addImages /
-    # sortImages / the per-view lanes run past both limits.  list_cap 32 = libmvskit_engine_cap32.so, what engine.Engine
-    # picks for more than 16 views; 16 = the default library forced onto the same scene.  The oracle truncates alike.
+    # BASELINE.json configs[3] has 48 views.  list_cap 64 = libmvskit_engine_cap64.so, what engine.Engine picks for more than 32
+    # views: no list is cut, as in the reference (optim.cpp:165-205 pushes every qualifying view).  32 / 16 = the smaller builds
+    # forced onto the same scene: more views than their records store or their lists keep, so addImages / sortImages / the
+    # per-view lanes run past both limits; the oracle truncates alike.
     sc = synth.make_scene(nviews=48, W=96, H=72, arc_deg=141.0, radius=4.0, kind="plane")
     seeds = synth.make_seeds(sc, stride=6, seed=31, views=range(0, 48, 5))
     c = _one_iteration_matches(sc, seeds, seed=6, list_cap=list_cap)
     assert c["patches"] > 200 and c["inserted"] > 50
 
 
-def test_cap32_library_two_iterations_with_check_and_filter():
+@pytest.mark.parametrize("list_cap,nviews", [(32, 20), (64, 40)])
+def test_many_view_libraries_two_iterations_with_check_and_filter(list_cap, nviews):
     """libmvskit_engine_cap32.so (32-view lists: twice the setRefImage LDS, eight rounds of pair lanes, two patches per wave
-    in filterExact) through the whole loop of PmMvps::run on a 20-view scene: counters, lists, maps and the four Filter::run
-    removal counts equal to the oracle's with the same cap."""
-    sc = synth.make_scene(nviews=20, W=160, H=120, arc_deg=120.0, radius=4.0, kind="multi")
-    seeds = synth.make_seeds(sc, stride=4, seed=3)
-    o, e = _pair(sc, seed=9, enable_check=1, list_cap=32)
-    assert e.list_cap == 32
+    in filterExact) on a 20-view scene and libmvskit_engine_cap64.so (64-view lists, 192-byte records, one view per lane, one
+    patch per wave in filterExact) on a 40-view scene, through the whole loop of PmMvps::run: counters, lists, maps and the four
+    Filter::run removal counts equal to the oracle's with the same cap."""
+    sc = synth.make_scene(nviews=nviews, W=160, H=120, arc_deg=120.0, radius=4.0, kind="multi")
+    seeds = synth.make_seeds(sc, stride=4 if nviews <= 20 else 6, seed=3)
+    o, e = _pair(sc, seed=9, enable_check=1, list_cap=list_cap)
+    assert e.list_cap == list_cap and e.dtype.itemsize == (192 if list_cap == 64 else 128)
     o.add_patches(seeds)
     e.upload_patches(seeds)
     longest = 0
@@ -354,7 +359,7 @@ def test_cap32_library_two_iterations_with_check_and_filter():
     po, pe = o.patches(), e.patches()
     assert po.shape == pe.shape and pe.shape[0] > seeds.shape[0]
     longest = int(pe["nimages"].max())
-    assert longest > 16  # lists beyond the default cap are really in play
+    assert longest > list_cap // 2  # lists beyond the next smaller cap are really in play
     np.testing.assert_array_equal(po["images"], pe["images"])
     np.testing.assert_array_equal(po["vimages"], pe["vimages"])
     np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
@@ -460,6 +465,34 @@ def test_filter_neighbor_dense_cells_take_the_retry_launch(small_plane_scene):
     np.testing.assert_array_equal(po["images"], pe["images"])
     np.testing.assert_array_equal(po["vimages"], pe["vimages"])
     np.testing.assert_array_equal(po["coord"], pe["coord"])
+    o.close()
+    e.close()
+
+
+def test_check_second_tier_dense_cells(small_plane_scene):
+    """Optim::check inside the sweep with neighbourhoods that do not fit a wave's LDS: cells that hold 30 patches (MAX_NUM_OF_PATCHES =
+    max_propag * csize^2 = 32 here, so the trim leaves them alone) give a candidate ~750 neighbours in its 5x5 cells, more than the
+    576 rows of the first tier.  Such destination cells give up in k_sweep and run again in k_sweep_retry with a 16384-slot id
+    set in global memory; the reference's findNeighbors is unbounded (patch_manager.cpp:671-728) and the oracle's table-size rule
+    is the same.  Counters, lists and coordinates equal the oracle's."""
+    sc = small_plane_scene
+    pool = _dense_pool(sc, per_cell=30, window=5)
+    o, e = _pair(sc, seed=4, enable_check=1, minImageNum=2, max_propag=8)
+    o.add_patches(pool)
+    e.upload_patches(pool)
+    o.update_threshold()
+    e.update_threshold()  # m_depth 2: Optim::check runs
+    co, ce = o.propagate(1), e.propagate(1)
+    t = e.timing()
+    assert t["check_retried_cells"] > 10, t
+    assert co == ce, (co, ce)
+    assert co["patches"] > 1000 and co["replaced"] > 100
+    po, pe = o.patches(), e.patches()
+    assert po.shape == pe.shape
+    np.testing.assert_array_equal(po["images"], pe["images"])
+    np.testing.assert_array_equal(po["vimages"], pe["vimages"])
+    np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+    assert (pe["coord"] == po["coord"]).all(axis=1).mean() > 0.99
     o.close()
     e.close()
 

@@ -170,12 +170,15 @@ def test_pmmvps_run_with_ranks_world1(host, small_multi_scene, tmp_path):
 
     plain, total_plain = run()
     idf = tmp_path / "comm.id"
+    idf.write_bytes(b"\0" * 160)  # what an earlier job that died may have left behind: replaced, never read
     host.mvshost_set_ranks(0, 1, str(idf).encode(), 0)
     try:
         ranked, total_ranked = run()
+        assert not idf.exists()  # rank 0 removes the id file once its communicator stands: a later job cannot pick it up
+        again, total_again = run()  # the same path a second time: a new id, a new file, the same patches
     finally:
         host.mvshost_set_ranks(0, 0, b"", 0)
-    assert idf.exists() and idf.stat().st_size == 128
+    assert not idf.exists() and total_again == total_ranked and again.tobytes() == ranked.tobytes()
     assert total_plain == total_ranked and total_plain > 5000
     assert plain.shape == ranked.shape and plain.shape[0] > seeds.shape[0]
     assert plain.tobytes() == ranked.tobytes()
