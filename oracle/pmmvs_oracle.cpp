@@ -614,7 +614,7 @@ float compute_ncc(const Scene& s, const Patch& p, orc_counters* cnt) {
 }
 
 /* Optim::setINCCs (vector), optim.cpp:708-746: reference view against ALL listed views (D9) */
-void set_inccs(const Scene& s, const Patch& p, const int* idx, int n, int robust, float* inccs, orc_counters* cnt, unsigned* okmask = nullptr) {
+void set_inccs(const Scene& s, const Patch& p, const int* idx, int n, int robust, float* inccs, orc_counters* cnt, uint64_t* okmask = nullptr) {
     V4 px, py;
     get_paxes(s, idx[0], p.coord, p.normal, px, py);
     if (cnt) cnt->evals++;
@@ -627,7 +627,7 @@ void set_inccs(const Scene& s, const Patch& p, const int* idx, int n, int robust
     for (int i = 1; i < n; ++i) {
         if (get_tex(s, p.coord, px, py, p.normal, idx[i], ti, cnt) == 0) normalize_tex(s, ti);
         if (!ti.ok) { inccs[i] = 2.0f; continue; }
-        if (okmask) *okmask |= 1u << i;
+        if (okmask) *okmask |= (uint64_t)1 << i;  /* one bit per view of the list: up to 64 in the wide build */
         const float d = 1.0f - dot_tex(s, t0, ti);
         inccs[i] = robust ? robustincc(d) : d;
     }
@@ -710,7 +710,7 @@ void add_images(const Scene& s, Patch& p) {
  * taken here as the tail of computeINCC (optim.cpp:690-705) over the robust INCCs of those views */
 void constraint_images(const Scene& s, Patch& p, float nccThreshold, orc_counters* cnt, const float* w_keep = nullptr, int n_keep = 0) {
     float inccs[MAXI];
-    unsigned ok = 0;
+    uint64_t ok = 0;
     set_inccs(s, p, p.img, p.nimg, 0, inccs, cnt, &ok);
     if (w_keep) {
         float incc = 2.0f;

@@ -228,9 +228,10 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
     (pmmvps.cpp:90-110) -- Propagate::run, Filter::run, updateThreshold, ++m_depth -- so Optim::check runs from the second
     iteration on and Filter::run five times at that size.  Too large for the oracle: the engine is held to the properties that do
     not depend on the size, and what it took (HBM, time per stage) is recorded in gpurun_out/config4_run.json.
-    Seeds: one per 32x32 cells per view (97 k) -- sparse on purpose: every patch sits in the cell lists of ~20 views, and the
-    index of a pool of P patches takes ~2 KB x P (60 B per membership, 32-bit offsets: P x list length < 2^31); mvs_config.max_patches
-    bounds P at 40 M here."""
+    Seeds: one per 4x4 cells in the central half x half of every view's grid (1.5 M seeds, a quarter of the cells): every patch sits
+    in the cell lists of ~36 of the 48 views, the index offsets are 32-bit (patches x views per patch < 2^31: at most ~55 M patches
+    at this list length; `mvs_engine_pass` reports MVS_ERR_CAPACITY beyond) and an index entry takes 60 bytes, so a pool grown over
+    ALL 99.5 M cells does not fit one card's index -- the seeded quarter does, at the same addressing, list lengths and kernels."""
     import json
     import os
     import time
@@ -239,10 +240,12 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
 
     sc = scene_48x4k
     n = sc.nviews
-    seeds = synth.make_seeds(sc, level=0, csize=2, stride=32, seed=777)
-    assert seeds.shape[0] > 80000 and len(set(seeds["images"][:, 0].tolist())) == n
+    seeds = synth.make_seeds(sc, level=0, csize=2, stride=4, seed=777)
+    cx, cy = _cells_in_ref_view(sc, seeds)
+    seeds = np.ascontiguousarray(seeds[(cx >= 480) & (cx < 1440) & (cy >= 270) & (cy < 810)])
+    assert seeds.shape[0] > 1_000_000 and len(set(seeds["images"][:, 0].tolist())) == n
     free0, total_mem = torch.cuda.mem_get_info(0)
-    e = engine.Engine(n, max_patches=40_000_000, **CFG)
+    e = engine.Engine(n, max_patches=60_000_000, **CFG)
     assert e.list_cap == 64 and e.dtype.itemsize == 192  # more than 32 views: libmvskit_engine_cap64.so
     e.set_scene(sc)
     assert e.grid_dims(47) == (1920, 1080)
@@ -262,7 +265,7 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
         peak = max(peak, (free0 - free1) / 2 ** 30)
         assert c["candidates"] == c["prefiltered"] + c["patches"], (it, c)
         assert c["patches"] == c["fail0"] + c["fail1"] + c["inserted"] + c["replaced"], (it, c)
-        assert c["patches"] > 100_000 and c["inserted"] > 50_000, (it, c)
+        assert c["patches"] > 1_000_000 and c["inserted"] > 500_000, (it, c)
         assert all(v >= 0 for v in f.values())
         log.append({"iteration": it, "counters": c, "propagate_s": t1 - t0, "timing_ms": t, "filter_removed": f, "filter_s": t2 - t1,
                     "filter_total_ms": fs["total_ms"], "pool_alive": e.num_patches(), "hbm_used_GiB": (free0 - free1) / 2 ** 30})
@@ -270,7 +273,7 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
     assert sum(sum(l["filter_removed"].values()) for l in log) > 0
     p = e.patches()
     made = p[p["dscale"] > 0]
-    assert made.shape[0] > 1_000_000
+    assert made.shape[0] > 5_000_000
     assert made["nimages"].min() >= CFG["minImageNum"] and made["nimages"].max() > 32  # lists longer than the 32-view build could keep
     k = np.arange(64)[None, :] < made["nimages"][:, None]
     imgs = np.where(k, made["images"], 255)
@@ -284,7 +287,7 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
     # depth map of the last view: the nearest patch of each cell
     depth, normal, ids = e.depth_normal_map(47, 0)
     have = ids >= 0
-    assert have.sum() > 10000
+    assert have.sum() > 100000
     oaxis = sc.P[47][2].astype(np.float64) / np.linalg.norm(sc.P[47][2, :3].astype(np.float64))
     row = np.full(int(p["id"].max()) + 1, -1, np.int64)
     row[p["id"]] = np.arange(p.shape[0])
@@ -292,7 +295,7 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
     np.testing.assert_allclose(depth[have], d, rtol=1e-5)
     assert peak < 288.0
     rec = {"views": n, "width": sc.W, "height": sc.H, "list_cap": e.list_cap, "record_bytes": int(e.dtype.itemsize), "cells": 48 * 1920 * 1080, "seeds": int(seeds.shape[0]),
-           "max_patches": 40_000_000, "iterations": log, "hbm_peak_GiB": peak, "hbm_total_GiB": total_mem / 2 ** 30, "pool_alive": int(p.shape[0]),
+           "max_patches": 60_000_000, "iterations": log, "hbm_peak_GiB": peak, "hbm_total_GiB": total_mem / 2 ** 30, "pool_alive": int(p.shape[0]),
            "mean_nimages": float(made["nimages"].mean()), "max_nimages": int(made["nimages"].max())}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)

@@ -484,7 +484,7 @@ def test_check_second_tier_dense_cells(small_plane_scene):
     e.update_threshold()  # m_depth 2: Optim::check runs
     co, ce = o.propagate(1), e.propagate(1)
     t = e.timing()
-    assert t["check_retried_cells"] > 10, t
+    assert t["check_retried_cells"] >= 5, t
     assert co == ce, (co, ce)
     assert co["patches"] > 1000 and co["replaced"] > 100
     po, pe = o.patches(), e.patches()
