@@ -575,7 +575,7 @@ DEV void eval_steps4(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const 
 // Leaves in view lane k >= 1 the INCC of view k against the reference view, okm[0] = views that sampled.
 // PIV: piv[0..2] receive, in view lane k, the channel means of view k (128 for a view that was not sampled) -- the
 // pivots of the class-lane steps that follow in refinePatch.
-// texs != nullptr: the centred texture of view k goes to LDS, texs[(3 k + channel) * tstride + sample], and *ssd_out
+// texs != nullptr: the centred texture of view k goes to LDS, texs[3 k tstride + 3 sample + channel], and *ssd_out
 // receives, in view lane k, its sum of squares -- what Optim::setRefImage needs.
 DEV void cls_raw(const ClsPend& p, unsigned cs, float& r, float& g, float& b) {  // bilinear blend; 0 on a slot without a sample
     const Texel2 q0 = p.q0, q1 = p.q1;
@@ -590,6 +590,9 @@ DEV void cls_raw(const ClsPend& p, unsigned cs, float& r, float& g, float& b) { 
 #define MVS_ROW_STEP2(C) { const float t0 = dpp0_f<C>(sq), t1 = dpp0_f<C>(dt); sq = sq + t0; dt = dt + t1; }
 #ifndef MVS_EV_PREFETCH
 #define MVS_EV_PREFETCH 1
+#endif
+#ifndef MVS_PAIR_MFMA
+#define MVS_PAIR_MFMA (MVS_LISTCAP > 16)  // setRefImage's pair sums on the matrix cores (the 32- and 64-view builds)
 #endif
 template <bool PIV = false>
 DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmask_t (&okm)[1], float& incc_l, float* piv = nullptr,
@@ -676,12 +679,12 @@ DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmas
             for (int j = 0; j < 3; ++j) pend[j] = cls_issue(fn, cls_opaque(cc.cs[j]));
         }
 #endif
-        if (texs && v < n) {
+        if (texs && v < n) {  // sample-major: element 3 q + channel of view v's row of 3 * tstride floats (the k order of the pair sums)
             float* tv = texs + (3 * v) * tstride;
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                if (cc.cs[j] >> 16) { const int q = lc + 16 * j; tv[q] = er[j]; tv[tstride + q] = eg[j]; tv[2 * tstride + q] = eb[j]; }
-            if (cc.nx > 0 && lc == 0) { tv[cc.xbase] = exr; tv[tstride + cc.xbase] = exg; tv[2 * tstride + cc.xbase] = exb; }
+                if (cc.cs[j] >> 16) { const int q = 3 * (lc + 16 * j); tv[q] = er[j]; tv[q + 1] = eg[j]; tv[q + 2] = eb[j]; }
+            if (cc.nx > 0 && lc == 0) { tv[3 * cc.xbase] = exr; tv[3 * cc.xbase + 1] = exg; tv[3 * cc.xbase + 2] = exb; }
         }
     }
     // lane 16 (v & 3) + (v >> 2): 1 / msd and the INCC of view v; then to view lane v
@@ -1158,14 +1161,57 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     const float inv_l = inv_msd(prm, ssd_l);
     WC_ADD(wc, 2)
     __syncthreads();
-    // one lane per pair (a, b), a < b < n: 120 pairs = 2 rounds of 64 lanes for 16 views (496 = 8 rounds for 32); the
-    // robust INCC of pair q goes to LDS behind the textures
+    // The pair products sum(k) t_a[k] t_b[k] over the 3 wsz elements of two centred textures, k = 3 sample + channel, as ONE
+    // k-ordered chain acc = fma(t_a[k], t_b[k], acc) (the reference sums sample by sample, optim.cpp:601-609) -- the order of a
+    // f32 MFMA, which is bit for bit such a chain (one rounding per product, no wider accumulator).  The robust INCC of pair
+    // q = pair_index(a, b) goes to LDS behind the textures.
     const int npairs = n * (n - 1) / 2;
+    (void)npairs;
 #if MVS_LISTCAP > 32
     float* pairv = texs + prm.list_n * 3 * tstride;   // behind the textures (the 64-view build sizes its LDS by the data set's view count)
 #else
     float* pairv = texs + MVS_LISTCAP * 3 * tstride;  // behind the textures
 #endif
+#if MVS_PAIR_MFMA
+    // The Gram matrix of the textures on the matrix cores: v_mfma_f32_32x32x2_f32 takes A[i][k] and B[k][j] from lane
+    // (i or j) + 32 k, one value each -- for T T^t the SAME value, t_i[2 s + (lane >> 5)] -- and leaves G[row][col = lane & 31],
+    // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), in accumulator register r.  Lists of more than 32 views take the three
+    // tiles (0,0), (0,1), (1,1) of the upper triangle, one after the other.
+    {
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        const int K = 3 * prm.wsz, tp = 3 * tstride;
+        const int li = wc.lane & 31, h = wc.lane >> 5;
+        const int nt = (n + 31) >> 5;
+        for (int bi = 0; bi < nt; ++bi)
+            for (int bj = bi; bj < nt; ++bj) {
+                const int vi = 32 * bi + li, vj = 32 * bj + li;
+                const float* pa = texs + __shfl(orig, min(vi, n - 1)) * tp + h;
+                const float* pb = texs + __shfl(orig, min(vj, n - 1)) * tp + h;
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (bi == bj) {
+                    for (int k = 0; k + 1 < K; k += 2) { const float a = pa[k]; acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0); }
+                } else {
+                    for (int k = 0; k + 1 < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+                }
+                if (K & 1) {  // the last element: the second k of the instruction multiplies zeros
+                    const float a = h ? 0.0f : pa[K - 1], b = h ? 0.0f : pb[K - 1];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
+                const int col = 32 * bj + li;
+                const float invb = __shfl(inv_l, min(col, n - 1));
+                const bool okb = col < n && ((okmask >> min(col, n - 1)) & 1u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float inva = __shfl(inv_l, min(row, n - 1));
+                    float val = robustincc(1.0f - (acc[r] * (inva * invb)) * prm.inv_3sz);
+                    if (!(okb && ((okmask >> min(row, n - 1)) & 1u))) val = 2.0f;
+                    if (row < col && col < n) pairv[pair_index(row, col, n)] = val;
+                }
+            }
+    }
+#else
+    // one lane per pair (a, b), a < b < n: 120 pairs = 2 rounds of 64 lanes for 16 views
     for (int r = 0; r * 64 < npairs; ++r) {
         const int q0 = wc.lane + 64 * r;
         int q = q0;
@@ -1176,13 +1222,15 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
         const float* ta = texs + (__shfl(orig, a) * 3) * tstride;
         const float* tb = texs + (__shfl(orig, b) * 3) * tstride;
         float acc = 0.0f;
-        for (int i = 0; i < prm.wsz; ++i)
-            acc += fma_(ta[2 * tstride + i], tb[2 * tstride + i], fma_(ta[tstride + i], tb[tstride + i], ta[i] * tb[i]));
+        for (int i = 0; i < 3 * prm.wsz; i += 3) {
+            acc = fma_(ta[i], tb[i], acc); acc = fma_(ta[i + 1], tb[i + 1], acc); acc = fma_(ta[i + 2], tb[i + 2], acc);
+        }
         const float inva = __shfl(inv_l, a), invb = __shfl(inv_l, b);
         float val = robustincc(1.0f - (acc * (inva * invb)) * prm.inv_3sz);
         if (!(act && ((okmask >> a) & 1u) && ((okmask >> b) & 1u))) val = 2.0f;
         if (act) pairv[q0] = val;
     }
+#endif
     __syncthreads();
     WC_ADD(wc, 3)
     // view lane i: sum over j of inccs[i][j], j ascending (std::accumulate, optim.cpp:368)

@@ -646,10 +646,18 @@ void set_inccs_matrix(const Scene& s, const Patch& p, const int* idx, int n, int
         for (int j = i + 1; j < n; ++j) {
             float val = 2.0f;
             if (t[i].ok && t[j].ok) {
-                /* the V x V pair products are always summed in the reference's sequential sample order
-                 * (optim.cpp:605-607), whatever sum_mode says: the engine gives one lane to each pair */
+                /* the V x V pair products run over the samples in the reference's sequential order (optim.cpp:605-607) in both
+                 * modes.  SEQ: the dot product of a sample's three channels, then added (Eigen's Vector3f::dot).  TREE64 (engine
+                 * arithmetic): ONE chain acc = fma(a[k], b[k], acc) over k = 3 sample + channel -- what a f32 MFMA computes (the
+                 * 32- and 64-view engine builds take the Gram matrix of the textures from v_mfma_f32_32x32x2_f32, which is bit
+                 * for bit a k-ordered fmaf chain; the 16-view build runs the same chain with one lane per pair) */
                 const int sz = s.cfg.wsize * s.cfg.wsize;
                 float acc = 0.0f;
+                if (s.cfg.sum_mode == ORC_SUM_TREE64) {
+                    for (int q = 0; q < sz; ++q) {
+                        acc = fma_(t[i].c[0][q], t[j].c[0][q], acc); acc = fma_(t[i].c[1][q], t[j].c[1][q], acc); acc = fma_(t[i].c[2][q], t[j].c[2][q], acc);
+                    }
+                } else
                 for (int q = 0; q < sz; ++q)
                     acc += fma_(t[i].c[2][q], t[j].c[2][q], fma_(t[i].c[1][q], t[j].c[1][q], t[i].c[0][q] * t[j].c[0][q]));
                 const float d = 1.0f - (acc * (t[i].inv * t[j].inv)) * s.inv_3sz;
