@@ -144,7 +144,9 @@ int mvs_engine_propagate(mvs_engine* e, int iter, mvs_counters* out);
 
 /* Filter::run (pmmvps/filter.cpp:25-49): filterOutside, filterExact, filterNeighbor(1), filterSmallGroups with the
  * depth-map / m_vimages rebuilds in between; removed4 = patches removed by each of the four.  filterSmallGroups
- * groups by connected components of the symmetrised neighbour relation. */
+ * groups by connected components of the symmetrised neighbour relation.
+ * With a communicator attached (mvs_engine_comm_init / _attach) the call is collective: every rank runs the per-patch stages
+ * on its share of the pool and the ranks exchange what the stages wrote; all ranks end with the same pool and the same counts. */
 int mvs_engine_filter(mvs_engine* e, int64_t* removed4);
 /* what the last mvs_engine_filter did: HIP-event time of each stage's kernel(s) and the work counts behind the
  * algorithmic-bytes model of DESIGN.md ("Filter::run"). */
@@ -161,6 +163,8 @@ typedef struct mvs_filter_stats {
     int64_t neighbor_visited;    /* distinct patches met: one 48-byte geometry gather each */
     int64_t neighbor_accepted;   /* neighbours handed to filterQuad */
     int64_t neighbor_retried;    /* patches whose neighbourhood did not fit the first launch's id set (second launch, 16384 slots) */
+    int64_t exchange_bytes;      /* multi-GPU: bytes this rank received from the others (kill bytes, rewritten records); the work counts
+                                  * above then cover this rank's share of the pool only */
 } mvs_filter_stats;
 int mvs_engine_filter_stats(mvs_engine* e, mvs_filter_stats* out);
 

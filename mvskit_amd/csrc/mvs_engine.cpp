@@ -170,6 +170,7 @@ struct mvs_engine {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     mvs_timing timing{};
     mvs_filter_stats fstats{};
+    int64_t fstats_exchange_bytes = 0;  // bytes this rank received in the last Filter::run's exchanges
     DevBuf<unsigned long long> fstat_buf;  // [1024][4] partial sums of Filter::filterNeighbor's work counts
     hipEvent_t fev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // multi-GPU (mvs_engine_comm_*): one RCCL communicator over the engines of the job
@@ -356,10 +357,44 @@ int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
 // setDepthMapsVGridsVPGridsAddPatchV between the stages of Filter::run.  The depth maps and m_vimages come from the pool; the two
 // grid indexes are built only for a stage that walks them: filterOutside (computeGain) reads m_pgrids, filterExact neither,
 // filterNeighbor and filterSmallGroups both -- and after the last stage the pool is compacted, which invalidates them anyway.
+// Filter::run over the ranks of a multi-GPU job: every stage is a per-patch kernel on a snapshot, so rank r runs it on the patches
+// [pool_n r / N, pool_n (r + 1) / N) and the ranks then hand each other what the stage wrote -- its kill bytes, and the records
+// themselves where it rewrote lists (filterExact: m_images; setVImagesVGrids: m_vimages) -- as in-place broadcasts of the ranges
+// (an all-gather-v without staging; ranges are contiguous and every rank computes the same bounds).  What works on the whole pool
+// at once stays replicated: the grid indexes, the depth maps, filterSmallGroups' union-find.  One rank: the whole pool, no exchange.
+void filter_range(const mvs_engine* e, int64_t& first, int64_t& last) {
+    first = 0; last = e->pool_n;
+    if (e->comm && e->comm_world > 1) {
+        first = e->pool_n * e->comm_rank / e->comm_world;
+        last = e->pool_n * (e->comm_rank + 1) / e->comm_world;
+    }
+}
+int filter_exchange(mvs_engine* e, bool kills, bool records) {
+    if (!e->comm || e->comm_world <= 1 || e->pool_n == 0) return MVS_OK;
+    const Rccl& R = rccl();
+    hipStream_t st = e->stream;
+    const int N = e->comm_world;
+    ncclResult_t first_err = R.GroupStart();
+    for (int r = 0; r < N && first_err == ncclSuccess; ++r) {
+        const int64_t lo = e->pool_n * r / N, hi = e->pool_n * (r + 1) / N;
+        if (hi <= lo) continue;
+        if (kills) first_err = R.Broadcast(e->kill.p + lo, e->kill.p + lo, (size_t)(hi - lo), ncclUint8, r, e->comm, st);
+        if (records && first_err == ncclSuccess)
+            first_err = R.Broadcast(e->pool.p + lo, e->pool.p + lo, (size_t)(hi - lo) * sizeof(DPatch), ncclUint8, r, e->comm, st);
+        e->fstats_exchange_bytes += (r == e->comm_rank) ? 0 : (kills ? (hi - lo) : 0) + (records ? (hi - lo) * (int64_t)sizeof(DPatch) : 0);
+    }
+    const ncclResult_t end = R.GroupEnd();
+    if (first_err == ncclSuccess) first_err = end;
+    if (first_err != ncclSuccess) { g_err = std::string("Filter::run exchange: ") + R.GetErrorString(first_err); return MVS_ERR_HIP; }
+    return MVS_OK;
+}
 int filter_rebuild(mvs_engine* e, int additive, bool need_pgrid, bool need_vpgrid) {
     if (need_pgrid) { if (int r = build_list(e, false, false)) return r; }
     if (int r = build_depth(e)) return r;
-    mvsk_filter_vimages(current_params(e), additive, e->stream);
+    int64_t first, last;
+    filter_range(e, first, last);
+    mvsk_filter_vimages(current_params(e), additive, first, last, e->stream);
+    if (int r = filter_exchange(e, false, true)) return r;  // m_vimages of the other ranks' patches
     if (need_vpgrid) { if (int r = build_list(e, true, false)) return r; }
     HIPCHK(hipGetLastError());
     return MVS_OK;
@@ -1091,10 +1126,14 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     if (int r = e->fstat_buf.ensure(4096)) return r;
     HIPCHK(hipMemsetAsync(e->fstat_buf.p, 0, 4096 * sizeof(unsigned long long), st));
     if (int r = mvs_engine_num_patches(e, &e->fstats.patches_in)) return r;
+    e->fstats_exchange_bytes = 0;
+    int64_t first = 0, last = 0;  // this rank's share of the pool (everything on one GPU)
     if (int r = filter_rebuild(e, 0, true, false)) return r;
     HIPCHK(hipEventRecord(e->fev[0], st));
-    mvsk_filter_outside(current_params(e), e->kill.p, st);                       // filterOutside
+    filter_range(e, first, last);
+    mvsk_filter_outside(current_params(e), e->kill.p, first, last, st);          // filterOutside
     HIPCHK(hipEventRecord(e->fev[1], st));
+    if (int r = filter_exchange(e, true, false)) return r;
     if (int r = apply_kills(e, &rem[0])) return r;
     // a stage that removed nothing leaves the depth maps, hence m_vimages (additive pass) and both grids, as they are
     if (rem[0] > 0) { if (int r = filter_rebuild(e, 1, false, false)) return r; }
@@ -1103,7 +1142,8 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     HIPCHK(hipEventRecord(e->fev[2], st));
 #ifdef MVS_STAGE_TIMING
     HIPCHK(hipMemsetAsync(e->counters.p, 0, sizeof(DCounters), st));
-    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, e->counters.p->stage, st);
+    filter_range(e, first, last);
+    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, e->counters.p->stage, first, last, st);
     {
         DCounters hc;
         HIPCHK(hipMemcpyAsync(&hc, e->counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
@@ -1114,7 +1154,8 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         fprintf(stderr, " (wave cycles %.3e)\n", (double)hc.stage[0]);
     }
 #else
-    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, nullptr, st);          // filterExact
+    filter_range(e, first, last);
+    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, nullptr, first, last, st);  // filterExact
 #endif
     HIPCHK(hipEventRecord(e->fev[3], st));
     {
@@ -1123,6 +1164,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         HIPCHK(hipStreamSynchronize(st));
         e->fstats.exact_view_evals = (int64_t)ev2[1];
     }
+    if (int r = filter_exchange(e, true, true)) return r;  // kill bytes + the rewritten m_images
     if (int r = apply_kills(e, &rem[1])) return r;
     if (int r = filter_rebuild(e, 1, true, true)) return r;
     e->fstats.neighbor_patches = e->fstats.exact_patches - rem[1];
@@ -1131,7 +1173,8 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         HIPCHK(hipMemsetAsync(e->misc.p + 4, 0, sizeof(unsigned long long), st));
         int32_t* nretry = reinterpret_cast<int32_t*>(e->misc.p + 4);
         HIPCHK(hipEventRecord(e->fev[4], st));
-        mvsk_filter_neighbor(current_params(e), e->kill.p, e->uf_parent.p, nretry, e->error_flag.p, e->fstat_buf.p, st);
+        filter_range(e, first, last);
+        mvsk_filter_neighbor(current_params(e), e->kill.p, e->uf_parent.p, nretry, e->error_flag.p, e->fstat_buf.p, first, last, st);
         int32_t nr = 0;
         HIPCHK(hipMemcpyAsync(&nr, nretry, sizeof nr, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1141,6 +1184,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         HIPCHK(hipGetLastError());  // a refused launch (LDS request) must not pass for "nothing to filter"
         HIPCHK(hipEventRecord(e->fev[5], st));
     }
+    if (int r = filter_exchange(e, true, false)) return r;
     if (int r = apply_kills(e, &rem[2])) return r;
     if (rem[2] > 0) { if (int r = filter_rebuild(e, 1, true, true)) return r; }
     {                                                                              // filterSmallGroups
@@ -1179,9 +1223,22 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         for (int b = 0; b < 1024; ++b) for (int k = 0; k < 4; ++k) sum4[k] += part[4 * b + k];
         f.neighbor_tasks = (int64_t)sum4[0]; f.neighbor_entries = (int64_t)sum4[1]; f.neighbor_visited = (int64_t)sum4[2]; f.neighbor_accepted = (int64_t)sum4[3];
     }
+    e->fstats.exchange_bytes = e->fstats_exchange_bytes;
     if (removed4) for (int k = 0; k < 4; ++k) removed4[k] = rem[k];
-    if (herr & 4) { g_err = "mvs_engine_filter: more than 14336 patches around one patch, or more than 4096 neighbours (engine limit)"; return MVS_ERR_CAPACITY; }
-    return MVS_OK;
+    int status = MVS_OK;
+    if (herr & 4) { g_err = "mvs_engine_filter: more than 14336 patches around one patch, or more than 4064 neighbours (engine limit)"; status = MVS_ERR_CAPACITY; }
+    if (e->comm && e->comm_world > 1) {  // a rank whose share met the engine's limit: every rank returns that status
+        if (int r = e->comm_counts.ensure(MVS_XCHG_WORDS * (1 + (int64_t)e->comm_world))) return r;
+        const int64_t mine = status;
+        std::vector<int64_t> all((size_t)e->comm_world);
+        HIPCHK(hipMemcpyAsync(e->comm_counts.p, &mine, sizeof mine, hipMemcpyHostToDevice, st));
+        NCCLCHK(rccl().AllGather(e->comm_counts.p, e->comm_counts.p + 1, 1, ncclInt64, e->comm, st));
+        HIPCHK(hipMemcpyAsync(all.data(), e->comm_counts.p + 1, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int r = 0; r < e->comm_world; ++r)
+            if (all[r] != MVS_OK && status == MVS_OK) { status = (int)all[r]; g_err = "mvs_engine_filter: rank " + std::to_string(r) + " met the engine's neighbourhood limit in its share of the pool"; }
+    }
+    return status;
 }
 
 int mvs_engine_filter_stats(mvs_engine* e, mvs_filter_stats* out) {

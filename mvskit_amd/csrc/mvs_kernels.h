@@ -31,10 +31,10 @@ void mvsk_apply_kill_ids(DPatch* pool, const int32_t* ids, int64_t n, int64_t po
 void mvsk_append_records(DPatch* pool, int64_t pool_n, const DPatch* recs, int64_t n, hipStream_t st);
 void mvsk_alive_count(const DPatch* pool, int64_t n, int32_t* cnt, hipStream_t st);
 void mvsk_alive_gather(const DPatch* pool, int64_t n, const int32_t* base, DPatch* out, int64_t cap, hipStream_t st);
-void mvsk_filter_vimages(const DParams& prm, int additive, hipStream_t st);
-void mvsk_filter_outside(const DParams& prm, uint8_t* kill, hipStream_t st);
-void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, hipStream_t st);
-void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, hipStream_t st);
+void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_t last, hipStream_t st);
+void mvsk_filter_outside(const DParams& prm, uint8_t* kill, int64_t first, int64_t last, hipStream_t st);
+void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, int64_t first, int64_t last, hipStream_t st);
+void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, int64_t first, int64_t last, hipStream_t st);
 void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* overflow, unsigned long long* stats, hipStream_t st);
 void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st);
 void mvsk_probe(const DParams& prm, int op, int64_t n, const DPatch* in, const float* in_f, DPatch* out, float* out_f, int32_t* out_i, hipStream_t st);

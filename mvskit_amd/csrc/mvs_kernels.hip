@@ -656,9 +656,10 @@ DEV void store_lists(DPatch* p, const WaveCtx& wc, const Cand& c) {
     }
 }
 // Filter::setVGridsVPGrids (filter.cpp:657-664): m_vimages cleared (additive == 0) or kept, then setVImagesVGrids
-__global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive) {
+// (all Filter::run kernels take a patch range [first, last): a rank of a multi-GPU job filters its share of the pool)
+__global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive, int64_t first) {
     __shared__ int s_scratch[192];
-    DPatch* p = prm.pool + blockIdx.x;
+    DPatch* p = prm.pool + first + blockIdx.x;
     if (!(p->flags & 1)) return;
     WaveCtx wc = make_wave_ctx(prm);
     Cand c;
@@ -669,10 +670,10 @@ __global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive
     store_lists(p, wc, c);
 }
 // Filter::filterOutside, filter.cpp:51-106: gain < 0 -> removed
-__global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kill) {
+__global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kill, int64_t first) {
     __shared__ int s_dummy[1];
     __shared__ int s_gain[MVS_LISTCAP];
-    const DPatch* p = prm.pool + blockIdx.x;
+    const DPatch* p = prm.pool + first + blockIdx.x;
     if (!(p->flags & 1)) return;
     WaveCtx wc = make_wave_ctx(prm);
     Cand c;
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kil
     set_vgrids(prm, wc, c);
     const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, nullptr};
     const float gain = compute_gain(prm, wc, cx, c, s_gain);
-    if (wc.lane == 0 && gain < 0.0f) kill[blockIdx.x] = 1;
+    if (wc.lane == 0 && gain < 0.0f) kill[first + blockIdx.x] = 1;
 }
 // Filter::filterExact, filter.cpp:148-263.
 // Visibility phase (filterExactSub: PatchManager::isVisible in the patch's cell and its four neighbours, per view of
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kil
 // Then, patch by patch: the surviving views in ascending order and Optim::setRefImage with the whole wave.
 #define MVS_FE_LANES (MVS_LISTCAP <= 16 ? 16 : (MVS_LISTCAP <= 32 ? 32 : 64))  // lanes per patch in the visibility phase
 #define MVS_FE_PATCHES (64 / MVS_FE_LANES)
-__global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage) {
+__global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, int64_t first, int64_t last) {
     __shared__ int s_scratch[192];
     extern __shared__ float s_texs[];
     WaveCtx wc = make_wave_ctx(prm);
@@ -700,8 +701,8 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
     WC_T0(wc)
 #endif
     const int q = wc.lane / MVS_FE_LANES, i = wc.lane % MVS_FE_LANES;
-    const int64_t id = (int64_t)blockIdx.x * MVS_FE_PATCHES + q;
-    const bool have = id < prm.pool_n;
+    const int64_t id = first + (int64_t)blockIdx.x * MVS_FE_PATCHES + q;
+    const bool have = id < last;
     const DPatch* pl = prm.pool + (have ? id : 0);
     const bool alive_l = have && (pl->flags & 1);
     const int nimg_l = alive_l ? min(pl->nimages, MVS_LISTCAP) : 0;
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
     const int tstride = prm.wsz;  // odd for 7x7 / 5x5 windows: the lane-per-pair reads of setRefImage fall in distinct banks
     for (int g = 0; g < MVS_FE_PATCHES; ++g) {
         if (!((alive_b >> ((MVS_FE_LANES * g) & 63)) & 1ull)) continue;
-        DPatch* p = prm.pool + ((int64_t)blockIdx.x * MVS_FE_PATCHES + g);
+        DPatch* p = prm.pool + (first + (int64_t)blockIdx.x * MVS_FE_PATCHES + g);
         Cand c;
         load_cand(p, wc, c);
         const vmask_t sm = (vmask_t)((safe_b >> ((MVS_FE_LANES * g) & 63)) & (MVS_FE_LANES == 64 ? ~0ull : (1ull << (MVS_FE_LANES & 63)) - 1ull));  // bit i: view m_images[i] of patch g survives
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
             set_ref_image(prm, wc, s_texs, tstride, c);
             store_lists(p, wc, c);
         } else {
-            if (wc.lane == 0) kill[(int64_t)blockIdx.x * MVS_FE_PATCHES + g] = 1;
+            if (wc.lane == 0) kill[first + (int64_t)blockIdx.x * MVS_FE_PATCHES + g] = 1;
         }
     }
     if (wc.lane == 0 && wc.evals) { atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
@@ -788,10 +789,10 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
 // does not fit is appended to `retry`.  Second launch: only those patches, with the large configuration.
 template <int HCAP, int RCAP>
 __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* retry, int32_t* nretry,
-                                                        int32_t* overflow, unsigned long long* stats /* [1024][4], spread over blocks */) {
+                                                        int32_t* overflow, unsigned long long* stats /* [1024][4], spread over blocks */, int64_t first) {
     extern __shared__ float s_lds[];
     int* const s_dummy = reinterpret_cast<int*>(s_lds);  // the live list of a destination cell: none here (live_view = -1), never read
-    const int64_t id = todo ? (blockIdx.x < (unsigned)ntodo ? todo[blockIdx.x] : -1) : (int64_t)blockIdx.x;
+    const int64_t id = todo ? (blockIdx.x < (unsigned)ntodo ? todo[blockIdx.x] : -1) : first + (int64_t)blockIdx.x;
     if (id < 0 || id >= prm.pool_n) return;
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
@@ -1040,24 +1041,24 @@ void mvsk_alive_count(const DPatch* pool, int64_t n, int32_t* cnt, hipStream_t s
 void mvsk_alive_gather(const DPatch* pool, int64_t n, const int32_t* base, DPatch* out, int64_t cap, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_alive_gather, dim3(nblk(n, 256)), dim3(256), 0, st, pool, n, base, out, cap);
 }
-void mvsk_filter_vimages(const DParams& prm, int additive, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_vimages, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, additive);
+void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_t last, hipStream_t st) {
+    if (last > first) hipLaunchKernelGGL(k_filter_vimages, dim3((unsigned)(last - first)), dim3(64), 0, st, prm, additive, first);
 }
-void mvsk_filter_outside(const DParams& prm, uint8_t* kill, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_outside, dim3((unsigned)prm.pool_n), dim3(64), 0, st, prm, kill);
+void mvsk_filter_outside(const DParams& prm, uint8_t* kill, int64_t first, int64_t last, hipStream_t st) {
+    if (last > first) hipLaunchKernelGGL(k_filter_outside, dim3((unsigned)(last - first)), dim3(64), 0, st, prm, kill, first);
 }
-void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)((prm.pool_n + MVS_FE_PATCHES - 1) / MVS_FE_PATCHES)), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals, stage);
+void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, int64_t first, int64_t last, hipStream_t st) {
+    if (last > first) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)((last - first + MVS_FE_PATCHES - 1) / MVS_FE_PATCHES)), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals, stage, first, last);
 }
-void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, hipStream_t st) {
-    if (prm.pool_n <= 0) return;
-    hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP>), dim3((unsigned)prm.pool_n), dim3(64),
-                       (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow, stats);
+void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, int64_t first, int64_t last, hipStream_t st) {
+    if (last <= first) return;
+    hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP>), dim3((unsigned)(last - first)), dim3(64),
+                       (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow, stats, first);
 }
 void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* overflow, unsigned long long* stats, hipStream_t st) {
     if (ntodo <= 0) return;
     hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP>), dim3((unsigned)ntodo), dim3(64),
-                       (size_t)MVS_SET_LDS_FLOATS(MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP) * sizeof(float), st, prm, kill, todo, ntodo, (int32_t*)nullptr, (int32_t*)nullptr, overflow, stats);
+                       (size_t)MVS_SET_LDS_FLOATS(MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP) * sizeof(float), st, prm, kill, todo, ntodo, (int32_t*)nullptr, (int32_t*)nullptr, overflow, stats, (int64_t)0);
 }
 void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st) {
     if (prm.pool_n <= 0) return;

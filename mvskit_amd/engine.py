@@ -58,7 +58,7 @@ class Timing(C.Structure):
 class FilterStats(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("outside_ms", "exact_ms", "neighbor_ms", "groups_ms", "rebuild_ms", "total_ms")] + \
                [(n, C.c_int64) for n in ("patches_in", "exact_patches", "exact_view_evals", "neighbor_patches", "neighbor_tasks", "neighbor_entries",
-                                         "neighbor_visited", "neighbor_accepted", "neighbor_retried")]
+                                         "neighbor_visited", "neighbor_accepted", "neighbor_retried", "exchange_bytes")]
 
 
 class EngineError(RuntimeError):

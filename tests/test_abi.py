@@ -70,9 +70,9 @@ def test_cap32_library_exports_the_same_abi():
 
 
 def test_struct_sizes_of_the_binding():
-    # mvs_timing: 3 floats, int32, float, (pad), 2 int64; mvs_filter_stats: 6 floats + 9 int64
+    # mvs_timing: 3 floats, int32, float, (pad), 2 int64; mvs_filter_stats: 6 floats + 10 int64
     assert C.sizeof(engine.Timing) == 40
-    assert C.sizeof(engine.FilterStats) == 24 + 9 * 8
+    assert C.sizeof(engine.FilterStats) == 24 + 10 * 8
 
 
 def test_loopback_transport_exports_what_the_engine_binds():

@@ -115,21 +115,25 @@ def _worker_c_abi(rank, world, out_dir):
     with open(uid_path, "rb") as f:
         uid = f.read()
     e.comm_init(uid, rank, world)
-    tot, moved = 0, 0
+    tot, moved, fmoved = 0, 0, 0
+    removed = []
     for it in range(ITERS):
         tot += e.propagate(it)["patches"]
         moved += e.timing()["exchange_bytes"]
+        removed.append(list(e.filter().values()))  # Filter::run, collective: this rank filters its share of the pool
+        fmoved += e.filter_stats()["exchange_bytes"]
         e.update_threshold()
     np.save(os.path.join(out_dir, f"pool_{rank}.npy"), e.patches().view(np.uint8))
-    np.save(os.path.join(out_dir, f"patches_{rank}.npy"), np.array([tot, moved]))
+    np.save(os.path.join(out_dir, f"patches_{rank}.npy"), np.array([tot, moved, fmoved]))
+    np.save(os.path.join(out_dir, f"removed_{rank}.npy"), np.array(removed))
     e.comm_release()
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_c_abi_exchange_ranks_equal_one_rank(tmp_path, world):
-    """mvs_engine_exchange with world > 1 on one GPU: `world` processes, contiguous job ranges, the engine's own exchange
-    (what bench.py --gpus N and PmMvps::setRanks use on a node) over the loopback transport; every rank must end with
-    exactly the pool of the one-rank run."""
+    """mvs_engine_exchange with world > 1 on one GPU: `world` processes, contiguous job ranges of equal work, the engine's own
+    exchange (what bench.py --gpus N and PmMvps::setRanks use on a node) over the loopback transport, and Filter::run after every
+    iteration with each rank filtering its share of the pool; every rank must end with exactly the pool of the one-rank run."""
     import subprocess
 
     from mvskit_amd import engine
@@ -141,14 +145,19 @@ def test_c_abi_exchange_ranks_equal_one_rank(tmp_path, world):
     e.set_scene(sc)
     e.upload_patches(seeds)
     patches = 0
+    removed = []
     for it in range(ITERS):
         patches += e.propagate(it)["patches"]
+        removed.append(list(e.filter().values()))
         e.update_threshold()
     single = e.patches()
     pools = [np.load(tmp_path / f"pool_{r}.npy").view(engine.PATCH_DTYPE).reshape(-1) for r in range(world)]
     stats = [np.load(tmp_path / f"patches_{r}.npy") for r in range(world)]
     assert int(sum(s[0] for s in stats)) == patches and patches > 2000
-    assert all(int(s[1]) > 0 for s in stats)  # every rank received blocks from the others
+    assert all(int(s[1]) > 0 and int(s[2]) > 0 for s in stats)  # every rank received blocks from the others, in the sweep and in Filter::run
+    assert sum(sum(r) for r in removed) > 0
+    for r in range(world):  # the four removal counts of every Filter::run, the same on every rank as on one
+        np.testing.assert_array_equal(np.load(tmp_path / f"removed_{r}.npy"), np.array(removed))
     for f in ("coord", "normal", "ncc", "dscale", "nimages", "images", "nvimages", "vimages"):
         for p in pools:
             np.testing.assert_array_equal(p[f], single[f], err_msg=f)
