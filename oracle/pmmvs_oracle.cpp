@@ -25,6 +25,7 @@
 #include "pmmvs_oracle.h"
 
 #include <algorithm>
+#include <iterator>
 #include <array>
 #include <atomic>
 #include <chrono>
@@ -1462,14 +1463,17 @@ void small_group_edges(const Scene& s, int pid, std::vector<int>& out) {
         }
     }
 }
-int filter_small_groups(Scene& s) {
+/* mode: 0 = the schedule's own labelling, 1 = the literal breadth-first labelling, 2 = components; dead_out: the patches that
+ * would be removed are listed there and the pool is left alone (orc_small_groups_compare), else they are removed */
+int filter_small_groups(Scene& s, int mode = 0, std::vector<int>* dead_out = nullptr) {
     std::vector<int> alive;
     for (size_t id = 0; id < s.pool.size(); ++id) if (s.pool[id].alive) alive.push_back((int)id);
     const int psize = (int)alive.size();
     if (psize == 0) return 0;
     std::vector<int> label(s.pool.size(), -1);
     int ngroups = 0;
-    if (s.cfg.schedule == ORC_SCHEDULE_FAITHFUL) {
+    const bool literal = mode == 1 || (mode == 0 && s.cfg.schedule == ORC_SCHEDULE_FAITHFUL);
+    if (literal) {
         for (int root : alive) {
             if (label[root] != -1) continue;
             const int id = ngroups++;
@@ -1502,7 +1506,10 @@ int filter_small_groups(Scene& s) {
     for (int pid : alive) ++size[label[pid]];
     const int threshold = std::max(20, psize / 10000);
     int removed = 0;
-    for (int pid : alive) if (size[label[pid]] < threshold) { s.pool[pid].alive = false; ++removed; }
+    for (int pid : alive) if (size[label[pid]] < threshold) {
+        if (dead_out) dead_out->push_back(pid); else s.pool[pid].alive = false;
+        ++removed;
+    }
     return removed;
 }
 
@@ -2148,6 +2155,57 @@ int orc_clear_patches(orc_scene* h) {
 }
 int64_t orc_list_truncations(orc_scene* h) { return h->s.list_truncations.load(); }
 int orc_list_storage(void) { return MAXI; }
+/* Filter::run with both labellings of its last stage compared on the pool that stage meets: out[0] = alive patches there, out[1] =
+ * removed by the connected components of the symmetrised relation (ENGINE schedule, the GPU), out[2] = removed by the reference's
+ * breadth-first labelling in patch order (filter.cpp:432-524), out[3] = removed by both; the schedule's own labelling is applied */
+int orc_small_groups_compare(orc_scene* h, int64_t* out) {
+    Scene& s = h->s;
+    /* Filter::run up to its fourth stage (filter.cpp:25-45), then both labellings side by side, then the schedule's own */
+    int64_t removed4[4];
+    filter_rebuild(s, 0);
+    removed4[0] = filter_outside(s);
+    filter_rebuild(s, 1);
+    removed4[1] = filter_exact(s);
+    filter_rebuild(s, 1);
+    removed4[2] = filter_neighbor(s);
+    filter_rebuild(s, 1);
+    std::vector<int> comp, lit;
+    filter_small_groups(s, 2, &comp);
+    filter_small_groups(s, 1, &lit);
+    std::sort(comp.begin(), comp.end()); std::sort(lit.begin(), lit.end());
+    std::vector<int> both;
+    std::set_intersection(comp.begin(), comp.end(), lit.begin(), lit.end(), std::back_inserter(both));
+    int64_t alive = 0;
+    for (const Patch& p : s.pool) alive += p.alive ? 1 : 0;
+    out[0] = alive; out[1] = (int64_t)comp.size(); out[2] = (int64_t)lit.size(); out[3] = (int64_t)both.size();
+    removed4[3] = filter_small_groups(s);
+    (void)removed4;
+    filter_rebuild(s, 1);
+    return 0;
+}
+/* Filter::filterSmallGroups' relation on the current pool (after a filter_rebuild): out[0] = alive patches, out[1] = directed edges
+ * p -> q (q != p), out[2] = those without the reverse edge q -> p */
+int orc_group_edge_stats(orc_scene* h, int64_t* out) {
+    Scene& s = h->s;
+    filter_rebuild(s, 1);
+    std::vector<std::vector<int>> adj(s.pool.size());
+    int64_t alive = 0, edges = 0, oneway = 0;
+    for (size_t id = 0; id < s.pool.size(); ++id) {
+        if (!s.pool[id].alive) continue;
+        ++alive;
+        small_group_edges(s, (int)id, adj[id]);
+        std::sort(adj[id].begin(), adj[id].end());
+        adj[id].erase(std::unique(adj[id].begin(), adj[id].end()), adj[id].end());
+    }
+    for (size_t id = 0; id < s.pool.size(); ++id)
+        for (int q : adj[id]) {
+            if (q == (int)id) continue;
+            ++edges;
+            if (!std::binary_search(adj[q].begin(), adj[q].end(), (int)id)) ++oneway;
+        }
+    out[0] = alive; out[1] = edges; out[2] = oneway;
+    return 0;
+}
 int orc_patch_bytes(void) { return (int)sizeof(orc_patch); }
 int orc_set_cell_budget(orc_scene* h, int64_t n) { h->s.cell_budget = n; return 0; }
 int orc_set_time_budget(orc_scene* h, double seconds) { h->s.time_budget = seconds; return 0; }

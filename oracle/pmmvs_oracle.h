@@ -124,6 +124,12 @@ int orc_filter(orc_scene* s, int64_t* removed4);
 int64_t orc_list_truncations(orc_scene* s); /* times a view list wanted to grow past list_cap since orc_create */
 int orc_list_storage(void);                 /* views a list can hold in this build: 32, or 64 in the wide build */
 int orc_patch_bytes(void);                  /* sizeof(orc_patch) in this build */
+/* orc_filter with its last stage, Filter::filterSmallGroups (filter.cpp:432-578), looked at twice: how the connected components the
+ * ENGINE schedule labels by compare with the reference's breadth-first labelling on the pool that stage meets (out[4]: alive,
+ * removed by components, by the literal labelling, by both); and the relation itself on the current pool (out[3]: alive,
+ * directed edges, edges without their reverse) */
+int orc_small_groups_compare(orc_scene* s, int64_t* out4);
+int orc_group_edge_stats(orc_scene* s, int64_t* out3);
 int orc_set_cell_budget(orc_scene* s, int64_t max_source_cells);
 int orc_set_time_budget(orc_scene* s, double seconds);
 double orc_last_sweep_seconds(orc_scene* h); /* engine schedule: wall time of the last colour pass's parallel loop */

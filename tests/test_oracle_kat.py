@@ -311,3 +311,37 @@ def test_list_cap_48_views():
     # views run on the 32-view build
     assert f32 > 0.5 and f32 > 2.0 * f16, (f16, f32)
     assert a32["median_rel_depth_diff"] <= 1e-6 and a16["median_rel_depth_diff"] < 5e-3
+
+
+def test_small_groups_components_vs_literal_labelling():
+    """Filter::filterSmallGroups (filter.cpp:432-524) labels groups by a breadth-first search in patch order over a DIRECTED relation (q
+    hangs on p when q is listed in the 3x3 cells around p in p's reference view and isNeighbor): the first unlabelled patch claims
+    everything it reaches, so a patch that reaches a surface but is reached by nothing forms a group of its own.  The ENGINE schedule
+    (and the GPU) label by the connected components of the symmetrised relation instead.  One edge in six has
+    no reverse edge, yet the two labellings remove almost the same patches: everything the components remove the literal labelling
+    removes too, and the literal labelling removes a handful more (less than 0.02 % of the pool).  Pinned here on the pools the
+    stage meets in the three Filter::run calls of a three-iteration run of the ENGINE schedule."""
+    import ctypes as C
+
+    sc = synth.make_scene(nviews=5, W=256, H=160, arc_deg=60.0, radius=4.0, kind="multi")
+    seeds = synth.make_seeds(sc, stride=3, seed=19)
+    o = ob.Oracle(sc.nviews, level=0, csize=2, wsize=7, minImageNum=3, schedule=ob.SCHEDULE_ENGINE, sum_mode=ob.SUM_TREE64, enable_check=1, nthreads=8, seed=21)
+    o.set_scene(sc)
+    o.add_patches(seeds)
+    o.L.orc_small_groups_compare.argtypes = [C.c_void_p, C.c_void_p]
+    o.L.orc_group_edge_stats.argtypes = [C.c_void_p, C.c_void_p]
+    extra = 0
+    for it in range(3):
+        o.propagate(it)
+        r = np.zeros(4, np.int64)
+        o.L.orc_small_groups_compare(o.h, r.ctypes.data_as(C.c_void_p))  # = o.filter(), with the comparison at its last stage
+        alive, comp, lit, both = (int(x) for x in r)
+        assert alive > 20000
+        assert both == comp <= lit                   # the components never remove a patch the reference's labelling keeps
+        assert lit - comp <= max(3, alive // 5000)   # and keep at most a few the reference would remove
+        extra += lit - comp
+        o.update_threshold()
+    st = np.zeros(3, np.int64)
+    o.L.orc_group_edge_stats(o.h, st.ctypes.data_as(C.c_void_p))
+    assert st[1] > 300000 and 0.05 < st[2] / st[1] < 0.3  # the relation really is directed: ~16 % of its edges are one-way
+    o.close()
