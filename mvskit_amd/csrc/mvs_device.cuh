@@ -1031,16 +1031,22 @@ DEV void cost_func4(const DParams& prm, WaveCtx& wc, const RefineCtx& rc, int im
         unsigned okm[4];
         eval_steps4(prm, wc, *cc, f, sz, okm, incc_l);
         const float val_l = robustincc(incc_l);
-        // the four means: one fp64 division for all of them (lane j divides the sums of proposal j)
-        double a[4];
-        int d[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sum_of_group(wc, okm[j], val_l, j, sz, a[j], d[j]);
-        const double num = wc.lane == 1 ? a[1] : (wc.lane == 2 ? a[2] : (wc.lane == 3 ? a[3] : a[0]));
-        const int den = wc.lane == 1 ? d[1] : (wc.lane == 2 ? d[2] : (wc.lane == 3 ? d[3] : d[0]));
+        // the four means, lane j < 4 = proposal j: its views' robust INCCs come over from the frame lanes 16 j + i one by one
+        // (ds_bpermute) and are added in the order of cost_func's loop (optim.cpp:451-465, i ascending, in double); one fp64
+        // division for all four
+        const int gl = wc.lane & 3;
+        const unsigned okl = gl == 1 ? okm[1] : (gl == 2 ? okm[2] : (gl == 3 ? okm[3] : okm[0]));
+        double num = 0.0;
+        int den = 0;
+        for (int i = 1; i < sz; ++i) {
+            const float v = bperm_f(4 * (16 * gl + i), val_l);
+            const bool ok = (okl >> i) & 1u;
+            num = ok ? num + (double)v : num;
+            den += ok ? 1 : 0;
+        }
         const double q = num / (double)den;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fv[j] = ((okm[j] & 1u) && d[j] >= minimum - 1) ? rld(q, j) : 2.0;
+        for (int j = 0; j < 4; ++j) fv[j] = ((okm[j] & 1u) && rli(den, j) >= minimum - 1) ? rld(q, j) : 2.0;
     } else {
         wc.evals += 1;
         vmask_t okm[1];

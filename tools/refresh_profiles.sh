@@ -2,12 +2,13 @@
 # tools/refresh_profiles.sh [round]: on a GPU box, regenerates what profiles/ holds for the current build
 # (run through gpurun; copies land in gpurun_out/profiles_new/, to be moved into profiles/ after review)
 set -e
-R=${1:-r02}
+R=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1"
-echo "== bench (with CPU baseline)"; timeout -k 10 500 $B > $out/${R}_bench_1gpu.json 2> $out/${R}_bench_1gpu.log
+B0="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1"
+B="$B0 --no-config5"
+echo "== bench (with CPU baseline and the config5 block)"; timeout -k 10 500 $B0 > $out/${R}_bench_1gpu.json 2> $out/${R}_bench_1gpu.log
 echo "== kernel trace"; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $B --cpu-seconds 0 > $out/kt.log 2>&1
 echo "== pmc fetch"; timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- $B --cpu-seconds 0 > $out/fetch.log 2>&1
 echo "== pmc write"; timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- $B --cpu-seconds 0 > $out/write.log 2>&1
@@ -24,4 +25,14 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_mix.py $(find $out/mixa $out/mixb $out/mixc $out/mixd -name "*counter_collection.csv") > $out/${R}_pmc_mix_k_sweep.json
 python3 tools/pmc_sq.py $(find $out/sq -name "*counter_collection.csv" | head -1) > $out/${R}_pmc_sq_k_sweep.json
-find $out -name "*.csv" | head -30
+echo "== many views: 48 x 960x540 on the 32-view and the 64-view build"
+M="--views 48 --width 960 --height 540"
+timeout -k 10 300 $B $M --list-cap 32 --cpu-seconds 0 > $out/${R}_bench_48x540p_cap32.json 2> $out/${R}_bench_48x540p_cap32.log
+timeout -k 10 300 $B $M --cpu-seconds 0 > $out/${R}_bench_48x540p.json 2> $out/${R}_bench_48x540p.log
+cd /tmp
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/sq48 -o sq48 -- $B $M --list-cap 32 --cpu-seconds 0 > $out/sq48.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/sq48c64 -o sq48c64 -- $B $M --cpu-seconds 0 > $out/sq48c64.log 2>&1
+cd $GRAFT_REPO_ROOT
+python3 tools/pmc_sq.py $(find $out/sq48 -name "*counter_collection.csv" | head -1) > $out/${R}_pmc_sq_k_sweep_48x540p_cap32.json
+python3 tools/pmc_sq.py $(find $out/sq48c64 -name "*counter_collection.csv" | head -1) > $out/${R}_pmc_sq_k_sweep_48x540p_cap64.json
+find $out -name "*.csv" | head -40
