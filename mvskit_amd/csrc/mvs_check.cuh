@@ -18,9 +18,9 @@ namespace mvsdev {
 // the accepted ids compacted to its front -- the 3 floats per neighbour filterQuad keeps, stored behind the ids.
 // 2048 slots (at most 7/8 visited) and 576 neighbours fit 9472 B, which with the 768 B of static LDS is 10 KB per wave:
 // 16 waves per CU.  The oracle picks the table size by the same rule (engine_neighbor_order).
-#if MVS_LISTCAP > 16
-// the 32-view build: its dynamic LDS is sized by setRefImage's kept textures (22 KB), so Optim::check's set can be twice as large
-// at no cost -- 32 views x 25 cells x two lists meet many more distinct patches (the oracle's rule: list_cap > 16)
+#if MVS_LISTCAP > 32
+// the 64-view build: its dynamic LDS is sized by setRefImage's chunk of 32 textures (22 KB), so Optim::check's set can be twice as
+// large at no cost -- 64 views x 25 cells x two lists meet many more distinct patches (the oracle's rule: list_cap > 32)
 #define MVS_HASH_CAP 4096
 #define MVS_ROW_CAP 1152
 #define MVS_CHECK_LDS_FLOATS 4672

@@ -30,6 +30,13 @@ struct F4 { float x, y, z, w; };
 #ifndef MVS_OUTLINE
 #define MVS_OUTLINE 0
 #endif
+// how far the texel loads run ahead of their use (1 = the next round / view only)
+#ifndef MVS_EV_DEPTH
+#define MVS_EV_DEPTH 1  // rounds of a single evaluation whose loads are in flight beyond the current one
+#endif
+#ifndef MVS_ST_DEPTH
+#define MVS_ST_DEPTH 1  // views of a refinement step whose loads are in flight beyond the current one
+#endif
 #if MVS_OUTLINE
 #define STAGE __device__ __noinline__
 #else
@@ -494,22 +501,35 @@ DEV void eval_steps4(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const 
     const int lc = wc.lane & 15;
     float c0[3][3];
     ClsPend pend[3];
+#if MVS_ST_DEPTH > 1
+    ClsPend ahead[3];  // the loads of the view after next (many-view builds: one or two waves per SIMD hide no latency)
+#endif
     float P1r, P1g, P1b, P2, P01 = 0.0f;
+    const int vlast = max(n - 1, 0);
     {
         const ClsFrame fr = cls_frame(fb);
 #pragma unroll
         for (int j = 0; j < 3; ++j) pend[j] = cls_issue(fr, cls_opaque(cc.cs[j]));
+#if MVS_ST_DEPTH > 1
+        const ClsFrame f1 = cls_frame(fb + min(1, vlast));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ahead[j] = cls_issue(f1, cls_opaque(cc.cs[j]));
+#endif
     }
     {   // the reference view
         const float4 pv = mvs_dyn_lds4[MVS_PIVOT_LDS4];
-        const ClsFrame fn = cls_frame(fb + min(1, max(n - 1, 0)));
+        const ClsFrame fn = cls_frame(fb + min(MVS_ST_DEPTH, vlast));
         float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const unsigned cs = cls_opaque(cc.cs[j]);
             float r, g, b;
             cls_colour(pend[j], cs, pv.x, pv.y, pv.z, r, g, b);
+#if MVS_ST_DEPTH > 1
+            pend[j] = ahead[j]; ahead[j] = cls_issue(fn, cs);
+#else
             pend[j] = cls_issue(fn, cs);
+#endif
             c0[j][0] = r; c0[j][1] = g; c0[j][2] = b;
             s1r += r; s1g += g; s1b += b;
             s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
@@ -519,14 +539,18 @@ DEV void eval_steps4(const DParams& prm, WaveCtx& wc, const ClsConst& cc, const 
     }
     for (int k = 1; k < n; ++k) {
         const float4 pv = mvs_dyn_lds4[MVS_PIVOT_LDS4 + k];
-        const ClsFrame fn = cls_frame(fb + min(k + 1, max(n - 1, 0)));
+        const ClsFrame fn = cls_frame(fb + min(k + MVS_ST_DEPTH, vlast));
         float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f, s2 = 0.0f, s01 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const unsigned cs = cls_opaque(cc.cs[j]);
             float r, g, b;
             cls_colour(pend[j], cs, pv.x, pv.y, pv.z, r, g, b);
+#if MVS_ST_DEPTH > 1
+            pend[j] = ahead[j]; ahead[j] = cls_issue(fn, cs);
+#else
             pend[j] = cls_issue(fn, cs);
+#endif
             s1r += r; s1g += g; s1b += b;
             s2 = fma_(r, r, s2); s2 = fma_(g, g, s2); s2 = fma_(b, b, s2);
             s01 = fma_(r, c0[j][0], s01); s01 = fma_(g, c0[j][1], s01); s01 = fma_(b, c0[j][2], s01);
@@ -591,12 +615,52 @@ DEV void cls_raw(const ClsPend& p, unsigned cs, float& r, float& g, float& b) { 
 #ifndef MVS_EV_PREFETCH
 #define MVS_EV_PREFETCH 1
 #endif
+
 #ifndef MVS_PAIR_MFMA
 #define MVS_PAIR_MFMA (MVS_LISTCAP > 16)  // setRefImage's pair sums on the matrix cores (the 32- and 64-view builds)
+#endif
+#if MVS_PAIR_MFMA
+// The Gram matrix G[a][b] = sum(k) t_a[k] t_b[k] of the kept textures is taken WHILE the views are sampled, in two chunks of
+// MVS_GRAM_CH views, so that only one chunk of textures lies in LDS at a time (the textures of a whole 32- or 64-view list were what
+// held these builds at one or two waves per SIMD).  Chunk A's textures are read once into registers in MFMA operand layout before
+// chunk B overwrites them; the tiles A x A, A x B, B x B each run down the k-ordered chain acc = fma(t_a[k], t_b[k], acc), which is
+// what v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32 compute.  G then replaces the textures in LDS (MVS_GRAM_LD floats per row).
+#define MVS_GRAM_CH (MVS_LISTCAP / 2)
+#define MVS_GRAM_LD MVS_LISTCAP
+#define MVS_GRAM_KK (MVS_GRAM_CH == 16 ? 4 : 2)                 // k values per MFMA: 16x16x4 or 32x32x2
+#define MVS_GRAM_KS ((147 + MVS_GRAM_KK - 1) / MVS_GRAM_KK)      // MFMAs per tile for a 7x7 window (3 * 49 elements): 37 or 74
+#define MVS_GRAM_NACC (MVS_GRAM_CH == 16 ? 4 : 16)               // accumulator registers of a tile
+typedef float gram_acc_t __attribute__((ext_vector_type(MVS_GRAM_NACC)));
+DEV gram_acc_t gram_mfma(float a, float b, gram_acc_t c) {
+#if MVS_LISTCAP == 32
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+// accumulator register r of lane l holds tile element (row, col)
+DEV int gram_col(int lane) { return lane & (MVS_GRAM_CH - 1); }
+DEV int gram_row(int lane, int r) {
+#if MVS_LISTCAP == 32
+    return (lane >> 4) * 4 + r;
+#else
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#endif
+}
 #endif
 template <bool PIV = false>
 DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmask_t (&okm)[1], float& incc_l, float* piv = nullptr,
                     float* texs = nullptr, int tstride = 0, float* ssd_out = nullptr) {
+#if MVS_PAIR_MFMA
+    // texs != nullptr: the Gram matrix of the centred textures is left at texs[a * MVS_GRAM_LD + b] (see MVS_GRAM_CH above)
+    float ta[MVS_GRAM_KS];  // chunk A in MFMA operand layout: lane l holds t_{l % CH}[KK s + l / CH] in ta[s]
+    gram_acc_t gAA, gAB, gBB;
+#pragma unroll
+    for (int r = 0; r < MVS_GRAM_NACC; ++r) { gAA[r] = 0.0f; gAB[r] = 0.0f; gBB[r] = 0.0f; }
+    const int gK = 3 * prm.wsz, gtp = 3 * tstride;
+    const int gk0 = wc.lane / MVS_GRAM_CH;                       // this lane's k within an MFMA
+    const float* const grow = texs + (wc.lane & (MVS_GRAM_CH - 1)) * gtp;  // this lane's view of the chunk in LDS
+#endif
     const ClsConst& cc = wc.cc;
     frames_publish(wc, f, MVS_LISTCAP > 16 ? MVS_LISTCAP : 16);
     okm[0] = vballot(f.ok != 0);  // a frame is only ever valid on a lane < n <= MVS_LISTCAP
@@ -616,18 +680,29 @@ DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmas
     float d0[3][3], d0x[3] = {0.0f, 0.0f, 0.0f};
     float ssd_l = 1.0f, dot_l = 0.0f, mr_l = 128.0f, mg_l = 128.0f, mb_l = 128.0f;
     ClsPend pend[3];
+#if MVS_EV_DEPTH > 1
+    ClsPend ahead[MVS_EV_DEPTH - 1][3];  // the loads of the rounds t + 1 .. t + MVS_EV_DEPTH - 1 (many-view builds: one or two waves per SIMD hide no latency)
+#endif
     {
         const int last = max(n - 1, 0);  // an empty list never reaches this point; the clamps below stay inside the frames all the same
         const ClsFrame fr = cls_frame(min(row, last));
 #pragma unroll
         for (int j = 0; j < 3; ++j) pend[j] = cls_issue(fr, cls_opaque(cc.cs[j]));
+#if MVS_EV_DEPTH > 1
+#pragma unroll
+        for (int d = 0; d < MVS_EV_DEPTH - 1; ++d) {
+            const ClsFrame fd = cls_frame(min(row + 4 * (d + 1), last));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ahead[d][j] = cls_issue(fd, cls_opaque(cc.cs[j]));
+        }
+#endif
     }
     if (cc.nx > 0) cls_raw(pe, xcs, fxr, fxg, fxb);
     const int rounds = (n + 3) >> 2;
     for (int t = 0; t < rounds; ++t) {
         const int v = 4 * t + row, vq = min(v, max(n - 1, 0));
 #if MVS_EV_PREFETCH
-        const ClsFrame fn = cls_frame(min(v + 4, max(n - 1, 0)));
+        const ClsFrame fn = cls_frame(min(v + 4 * MVS_EV_DEPTH, max(n - 1, 0)));
 #endif
         float cr[3], cg[3], cb[3];
         float s1r = 0.0f, s1g = 0.0f, s1b = 0.0f;
@@ -636,7 +711,14 @@ DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmas
             const unsigned cs = cls_opaque(cc.cs[j]);
             cls_raw(pend[j], cs, cr[j], cg[j], cb[j]);
 #if MVS_EV_PREFETCH
+#if MVS_EV_DEPTH > 1
+            pend[j] = ahead[0][j];
+#pragma unroll
+            for (int d = 0; d + 1 < MVS_EV_DEPTH - 1; ++d) ahead[d][j] = ahead[d + 1][j];
+            ahead[MVS_EV_DEPTH - 2][j] = cls_issue(fn, cs);
+#else
             pend[j] = cls_issue(fn, cs);
+#endif
 #endif
             s1r += cr[j]; s1g += cg[j]; s1b += cb[j];
         }
@@ -679,6 +761,45 @@ DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmas
             for (int j = 0; j < 3; ++j) pend[j] = cls_issue(fn, cls_opaque(cc.cs[j]));
         }
 #endif
+#if MVS_PAIR_MFMA
+        if (texs) {  // sample-major: element 3 q + channel of the view's row of 3 * tstride floats (the k order of the pair sums); slot = view % CH
+            float* tv = texs + (3 * (v & (MVS_GRAM_CH - 1))) * tstride;
+            const bool have = v < n;  // rows without a view hold zeros: their products vanish and are never looked at
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (cc.cs[j] >> 16) { const int q = 3 * (lc + 16 * j); tv[q] = have ? er[j] : 0.0f; tv[q + 1] = have ? eg[j] : 0.0f; tv[q + 2] = have ? eb[j] : 0.0f; }
+            if (cc.nx > 0 && lc == 0) { tv[3 * cc.xbase] = have ? exr : 0.0f; tv[3 * cc.xbase + 1] = have ? exg : 0.0f; tv[3 * cc.xbase + 2] = have ? exb : 0.0f; }
+            const bool endA = 4 * (t + 1) == MVS_GRAM_CH, last = t + 1 == rounds;
+            if (endA || (last && 4 * rounds < MVS_GRAM_CH)) {  // chunk A is complete (or the list ends inside it): to registers, and A x A
+                __syncthreads();
+                // rows of chunk A that no round wrote (list shorter than the chunk) must read as zeros
+                for (int vz = 4 * (t + 1) + (wc.lane >> 4); vz < MVS_GRAM_CH; vz += 4)
+                    for (int q = lc; q < gtp; q += 16) texs[vz * gtp + q] = 0.0f;
+                __syncthreads();
+#pragma unroll
+                for (int sI = 0; sI < MVS_GRAM_KS; ++sI) {
+                    const int k = MVS_GRAM_KK * sI + gk0;
+                    ta[sI] = k < gK ? grow[k] : 0.0f;
+                    gAA = gram_mfma(ta[sI], ta[sI], gAA);
+                }
+                __syncthreads();
+            }
+            if (last && 4 * rounds > MVS_GRAM_CH) {  // chunk B: B x B from LDS, A x B with chunk A from the registers
+                __syncthreads();
+                for (int vz = 4 * rounds - MVS_GRAM_CH + (wc.lane >> 4); vz < MVS_GRAM_CH; vz += 4)
+                    for (int q = lc; q < gtp; q += 16) texs[vz * gtp + q] = 0.0f;
+                __syncthreads();
+#pragma unroll
+                for (int sI = 0; sI < MVS_GRAM_KS; ++sI) {
+                    const int k = MVS_GRAM_KK * sI + gk0;
+                    const float tb = k < gK ? grow[k] : 0.0f;
+                    gBB = gram_mfma(tb, tb, gBB);
+                    gAB = gram_mfma(ta[sI], tb, gAB);
+                }
+                __syncthreads();
+            }
+        }
+#else
         if (texs && v < n) {  // sample-major: element 3 q + channel of view v's row of 3 * tstride floats (the k order of the pair sums)
             float* tv = texs + (3 * v) * tstride;
 #pragma unroll
@@ -686,7 +807,23 @@ DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmas
                 if (cc.cs[j] >> 16) { const int q = 3 * (lc + 16 * j); tv[q] = er[j]; tv[q + 1] = eg[j]; tv[q + 2] = eb[j]; }
             if (cc.nx > 0 && lc == 0) { tv[3 * cc.xbase] = exr; tv[3 * cc.xbase + 1] = exg; tv[3 * cc.xbase + 2] = exb; }
         }
+#endif
     }
+#if MVS_PAIR_MFMA
+    if (texs) {  // the tiles to LDS over the textures: G[a][b], a and b in the order of this evaluation's list
+        __syncthreads();
+        const int col = gram_col(wc.lane);
+#pragma unroll
+        for (int r = 0; r < MVS_GRAM_NACC; ++r) {
+            const int row = gram_row(wc.lane, r);
+            texs[row * MVS_GRAM_LD + col] = gAA[r];
+            texs[row * MVS_GRAM_LD + MVS_GRAM_CH + col] = gAB[r];
+            texs[(MVS_GRAM_CH + col) * MVS_GRAM_LD + row] = gAB[r];
+            texs[(MVS_GRAM_CH + row) * MVS_GRAM_LD + MVS_GRAM_CH + col] = gBB[r];
+        }
+        __syncthreads();
+    }
+#endif
     // lane 16 (v & 3) + (v >> 2): 1 / msd and the INCC of view v; then to view lane v
     const float inv_l = inv_msd(prm, ssd_l);
     const float inv0 = rlf(inv_l, 0);
@@ -844,6 +981,7 @@ struct KeptTex {
     float ssd;       // view lanes (old index)
     vmask_t okm;     // bit k: old view k sampled
     int orig;        // view lanes (current index) -> old index
+    int n_eval;      // length of the list at the time of the evaluation
 };
 DEV void constraint_images(const DParams& prm, WaveCtx& wc, int* scratch, Cand& c, float nccThreshold, float keep_w = 0.0f, int keep_n = 0,
                            KeptTex* kt = nullptr) {
@@ -853,7 +991,7 @@ DEV void constraint_images(const DParams& prm, WaveCtx& wc, int* scratch, Cand& 
     if (keep_n > 0) c.ncc = 1.0f - unrobustincc(weighted_incc(prm, okm, robustincc(inccs), keep_w, keep_n));
     const bool keep = wc.lane == 0 || (wc.lane < c.nimg && inccs < 1.0f - nccThreshold);
     if (kt) {
-        kt->ssd = ssd; kt->okm = okm; kt->orig = wc.lane;
+        kt->ssd = ssd; kt->okm = okm; kt->orig = wc.lane; kt->n_eval = c.nimg;
         (void)compact1(scratch, wc, keep, kt->orig);
     }
     c.nimg = compact1(scratch, wc, keep, c.img);
@@ -1171,50 +1309,29 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     // k-ordered chain acc = fma(t_a[k], t_b[k], acc) (the reference sums sample by sample, optim.cpp:601-609) -- the order of a
     // f32 MFMA, which is bit for bit such a chain (one rounding per product, no wider accumulator).  The robust INCC of pair
     // q = pair_index(a, b) goes to LDS behind the textures.
+#if !MVS_PAIR_MFMA
     const int npairs = n * (n - 1) / 2;
-    (void)npairs;
-#if MVS_LISTCAP > 32
-    float* pairv = texs + prm.list_n * 3 * tstride;   // behind the textures (the 64-view build sizes its LDS by the data set's view count)
-#else
     float* pairv = texs + MVS_LISTCAP * 3 * tstride;  // behind the textures
 #endif
 #if MVS_PAIR_MFMA
-    // The Gram matrix of the textures on the matrix cores: v_mfma_f32_32x32x2_f32 takes A[i][k] and B[k][j] from lane
-    // (i or j) + 32 k, one value each -- for T T^t the SAME value, t_i[2 s + (lane >> 5)] -- and leaves G[row][col = lane & 31],
-    // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), in accumulator register r.  Lists of more than 32 views take the three
-    // tiles (0,0), (0,1), (1,1) of the upper triangle, one after the other.
+    // The evaluation left the Gram matrix of its textures at texs[a * MVS_GRAM_LD + b] (eval_views).  Row by row, lane b > a turns
+    // G[a][b] into the robust INCC of the pair (both triangles); `ne` = the list length of that evaluation, its views' 1 / msd and
+    // sampled bits by evaluation-time index.
     {
-        typedef float f32x16 __attribute__((ext_vector_type(16)));
-        const int K = 3 * prm.wsz, tp = 3 * tstride;
-        const int li = wc.lane & 31, h = wc.lane >> 5;
-        const int nt = (n + 31) >> 5;
-        for (int bi = 0; bi < nt; ++bi)
-            for (int bj = bi; bj < nt; ++bj) {
-                const int vi = 32 * bi + li, vj = 32 * bj + li;
-                const float* pa = texs + __shfl(orig, min(vi, n - 1)) * tp + h;
-                const float* pb = texs + __shfl(orig, min(vj, n - 1)) * tp + h;
-                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                if (bi == bj) {
-                    for (int k = 0; k + 1 < K; k += 2) { const float a = pa[k]; acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0); }
-                } else {
-                    for (int k = 0; k + 1 < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
-                }
-                if (K & 1) {  // the last element: the second k of the instruction multiplies zeros
-                    const float a = h ? 0.0f : pa[K - 1], b = h ? 0.0f : pb[K - 1];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-                }
-                const int col = 32 * bj + li;
-                const float invb = __shfl(inv_l, min(col, n - 1));
-                const bool okb = col < n && ((okmask >> min(col, n - 1)) & 1u);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float inva = __shfl(inv_l, min(row, n - 1));
-                    float val = robustincc(1.0f - (acc[r] * (inva * invb)) * prm.inv_3sz);
-                    if (!(okb && ((okmask >> min(row, n - 1)) & 1u))) val = 2.0f;
-                    if (row < col && col < n) pairv[pair_index(row, col, n)] = val;
-                }
+        const int ne = kt ? kt->n_eval : n;
+        const float inv_e = kt ? inv_msd(prm, kt->ssd) : inv_l;
+        const vmask_t ok_e = kt ? kt->okm : okmask;
+        const bool okb = wc.lane < ne && ((ok_e >> (wc.lane & (MVS_VBITS - 1))) & 1u);
+        for (int a = 0; a + 1 < ne; ++a) {
+            const float inva = rlf(inv_e, a);
+            const bool oka = (ok_e >> a) & 1u;
+            if (wc.lane > a && wc.lane < ne) {
+                float val = robustincc(1.0f - (texs[a * MVS_GRAM_LD + wc.lane] * (inva * inv_e)) * prm.inv_3sz);
+                if (!(oka && okb)) val = 2.0f;
+                texs[a * MVS_GRAM_LD + wc.lane] = val;
+                texs[wc.lane * MVS_GRAM_LD + a] = val;
             }
+        }
     }
 #else
     // one lane per pair (a, b), a < b < n: 120 pairs = 2 rounds of 64 lanes for 16 views
@@ -1241,6 +1358,15 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     WC_ADD(wc, 3)
     // view lane i: sum over j of inccs[i][j], j ascending (std::accumulate, optim.cpp:368)
     float acc = 0.0f;
+#if MVS_PAIR_MFMA
+    {
+        const int oi = wc.lane < n ? orig : 0;  // where view i sat in the evaluation whose matrix this is
+        for (int j = 0; j < n; ++j) {
+            const float v = texs[oi * MVS_GRAM_LD + rli(orig, j)];
+            if (wc.lane < n && wc.lane != j) acc += v;
+        }
+    }
+#else
     for (int j = 0; j < n; ++j) {
         const int i = min(wc.lane, n - 1);
         const int a = min(i, j), b = max(i, j);
@@ -1248,6 +1374,7 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
         const float v = pairv[q];
         if (wc.lane < n && wc.lane != j) acc += v;
     }
+#endif
     const float big = (float)(INT_MAX / 2);
     const bool cand = wc.lane < n && acc < big;
     const float m = wave_min(cand ? acc : __int_as_float(0x7f800000));
@@ -1319,7 +1446,7 @@ STAGE int post_process(const DParams& prm, WaveCtx& wc, int* scratch, float* tex
     add_images(prm, wc, scratch, c);
     // the textures of this evaluation stay in LDS (behind the frame region, which the evaluation itself uses) for setRefImage
     KeptTex kt;
-    kt.texs = texs + MVS_FRAME1_LDS_BYTES / 4; kt.tstride = tstride; kt.ssd = 1.0f; kt.okm = 0u; kt.orig = wc.lane;
+    kt.texs = texs + MVS_FRAME1_LDS_BYTES / 4; kt.tstride = tstride; kt.ssd = 1.0f; kt.okm = 0u; kt.orig = wc.lane; kt.n_eval = 0;
     constraint_images(prm, wc, scratch, c, prm.nccThreshold, keep_w, keep_n, &kt);
     filter_images_by_angle(prm, wc, scratch, c, &kt);
     if (c.nimg < prm.minImageNum) return -1;

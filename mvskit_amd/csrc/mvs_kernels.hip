@@ -353,9 +353,9 @@ __global__ void k_job_cuts(const int32_t* __restrict__ scan, int64_t njobs, int 
     }
 }
 
-#if !defined(MVS_SWEEP_WAVES) && MVS_LISTCAP > 16
-// the 32-view build: 22 KB of LDS per wave allow 7 waves per CU whatever the registers, so the allocator gets the 256 VGPRs of
-// two waves per SIMD and spills nothing (9.12 -> 10.08 M patches/s on the 48-view scene)
+#if !defined(MVS_SWEEP_WAVES) && MVS_LISTCAP > 32
+// the 64-view build: 22 KB of LDS per wave (one chunk of 32 textures) allow 7 waves per CU whatever the registers, and chunk A of
+// the Gram matrix waits in 74 registers: the allocator gets the 256 VGPRs of two waves per SIMD
 #define MVS_SWEEP_WAVES 2
 #endif
 #ifndef MVS_SWEEP_WAVES
@@ -987,14 +987,16 @@ void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_fill_ncc, dim3((unsigned)((prm.pool_n + 63) / 64)), dim3(64), MVS_FRAME_LDS_BYTES, st, prm, evals);
 }
 size_t mvsk_sweep_lds_bytes(const DParams& prm) {
-    // setRefImage: the centred textures of MVS_LISTCAP views (9408 B at wsize 7 and 16 views) + one value per view pair
-    // in postProcess they lie behind the frame region (the evaluation that produces them publishes its frames there)
-#if MVS_LISTCAP > 32
-    const size_t ln = (size_t)prm.list_n;  // the 64-view build: no list is longer than the data set has views
+    // setRefImage: the centred textures of MVS_LISTCAP views (9408 B at wsize 7 and 16 views) + one value per view pair;
+    // in postProcess they lie behind the frame region (the evaluation that produces them publishes its frames there).
+    // The 32- and 64-view builds keep one chunk of MVS_GRAM_CH views at a time and overlay the Gram matrix on it (mvs_device.cuh).
+#if MVS_PAIR_MFMA
+    const size_t tex_f = (size_t)MVS_GRAM_CH * 3 * prm.wsz, gram_f = (size_t)MVS_GRAM_LD * MVS_GRAM_LD;
+    const size_t texs = MVS_FRAME1_LDS_BYTES + (tex_f > gram_f ? tex_f : gram_f) * sizeof(float);
 #else
     const size_t ln = MVS_LISTCAP;
-#endif
     const size_t texs = MVS_FRAME1_LDS_BYTES + (ln * 3 * prm.wsz + ln * (ln - 1) / 2) * sizeof(float);
+#endif
     const size_t chk = (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float);                      // Optim::check hash set + rows
     const size_t need = texs > chk ? texs : chk;
     return need > (size_t)MVS_FRAME_LDS_BYTES ? need : (size_t)MVS_FRAME_LDS_BYTES;  // the frames + pivots of a refinement step
