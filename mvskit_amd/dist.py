@@ -70,9 +70,10 @@ class HostExchange:
         dist.all_gather(lst, mine, group=self.group)
         counts = torch.stack(lst)
         max_new, max_kill = int(counts[:, nviews].max()), int(counts[:, nviews + 1].max())
-        rec_bytes = np.zeros((max(max_new, 1), RECORD_BYTES), dtype=np.uint8)
+        rb = int(new_recs.dtype.itemsize) if new_recs.dtype.itemsize > 1 else (new_recs.shape[1] if new_recs.ndim == 2 else RECORD_BYTES)  # 128, or 192 (64-view library)
+        rec_bytes = np.zeros((max(max_new, 1), rb), dtype=np.uint8)
         if new_recs.shape[0]:
-            rec_bytes[: new_recs.shape[0]] = new_recs.view(np.uint8).reshape(-1, RECORD_BYTES)
+            rec_bytes[: new_recs.shape[0]] = new_recs.view(np.uint8).reshape(-1, rb)
         g = [torch.zeros(rec_bytes.shape, dtype=torch.uint8) for _ in range(world)]
         dist.all_gather(g, torch.from_numpy(rec_bytes), group=self.group)
         kpad = np.full(max(max_kill, 1), -1, dtype=np.int32)
@@ -80,7 +81,7 @@ class HostExchange:
         gk = [torch.zeros(kpad.shape, dtype=torch.int32) for _ in range(world)]
         dist.all_gather(gk, torch.from_numpy(kpad), group=self.group)
         parts = merge_in_view_order([t.numpy() for t in g], [counts[r, :nviews].numpy() for r in range(world)], nviews, world)
-        allrec = np.concatenate(parts) if parts else np.zeros((0, RECORD_BYTES), np.uint8)
+        allrec = np.concatenate(parts) if parts else np.zeros((0, rb), np.uint8)
         allkill = np.concatenate([gk[r].numpy()[: int(counts[r, nviews + 1])] for r in range(world)]) if max_kill else np.zeros(0, np.int32)
         return allrec, allkill
 
@@ -113,7 +114,7 @@ class HostStaged:
     def export_new(self):
         torch = self.torch
         n_new, n_kill, per_view = self.e.export_counts()
-        rec = torch.zeros(max(n_new, 1), RECORD_BYTES, dtype=torch.uint8, device=self.device)
+        rec = torch.zeros(max(n_new, 1), self.e.dtype.itemsize, dtype=torch.uint8, device=self.device)  # 128 bytes, 192 with the 64-view library
         kil = torch.full((max(n_kill, 1),), -1, dtype=torch.int32, device=self.device)
         torch.cuda.synchronize(self.device)
         self.e.export_device(rec.data_ptr(), rec.shape[0], kil.data_ptr(), kil.shape[0])
@@ -125,7 +126,7 @@ class HostStaged:
 
     def commit(self, recs, kills):
         torch = self.torch
-        r = torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(-1, RECORD_BYTES).copy()).to(self.device)
+        r = torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(-1, self.e.dtype.itemsize).copy()).to(self.device)
         k = torch.from_numpy(np.ascontiguousarray(kills, dtype=np.int32).copy()).to(self.device)
         torch.cuda.synchronize(self.device)
         self.e.commit_device(r.data_ptr(), r.shape[0], k.data_ptr(), k.shape[0])
@@ -163,9 +164,7 @@ class HostStagedExchange:
     host copy / all-gather over gloo / commit_device.  Same call shape as EngineExchange."""
 
     def __init__(self, engine, device, nviews, group=None):
-        from .synth import PATCH_DTYPE
-
-        self.e, self.nviews, self.dtype = engine, nviews, PATCH_DTYPE
+        self.e, self.nviews, self.dtype = engine, nviews, engine.dtype
         self.staged = HostStaged(engine, device)
         self.ex = HostExchange(group)
         self.last_timing = {}
