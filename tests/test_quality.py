@@ -59,6 +59,39 @@ def test_engine_reconstructs_the_scene(small_multi_scene):
     assert np.median(ang) < 8.0 and np.median(made["ncc"]) > 0.95
 
 
+@pytest.mark.gpu
+def test_many_view_engines_reconstruct_the_scene():
+    """The same ground-truth check for the many-view builds, whose setRefImage goes through the matrix cores: 40 views (the 64-view
+    library: no list cut, lists of up to 40 views) and the first 24 of them (the 32-view library), three iterations of PmMvps::run's
+    loop with Optim::check and Filter::run.  Independent of the oracle: the patches must lie on the analytic surface, closer than
+    the seeds."""
+    from mvskit_amd import engine
+
+    full = synth.make_scene(nviews=40, W=256, H=160, arc_deg=120.0, radius=4.0, kind="multi")
+    for nv, cap in ((40, 64), (24, 32)):
+        sc = synth.Scene(W=full.W, H=full.H, P=full.P[:nv], images=full.images[:nv], centers=full.centers[:nv], points=full.points[:nv],
+                         normals=full.normals[:nv], meta=full.meta)
+        seeds = synth.make_seeds(sc, stride=4, seed=19)
+        rel0, _ = patch_errors(sc, seeds)
+        e = engine.Engine(nv, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=3)
+        assert e.list_cap == cap
+        e.set_scene(sc)
+        e.upload_patches(seeds)
+        for it in range(3):
+            e.propagate(it)
+            e.filter()
+            e.update_threshold()
+        p = e.patches()
+        made = p[p["dscale"] > 0]
+        assert made.shape[0] > 3 * seeds.shape[0] and int(made["nimages"].max()) > cap // 2, (made.shape[0], int(made["nimages"].max()))
+        rel, ang = patch_errors(sc, made)
+        # one pixel of the 256-pixel-wide views is ~3e-3 of the depth
+        assert np.median(rel) < 0.8 * np.median(rel0), (nv, np.median(rel), np.median(rel0))
+        assert np.median(rel) < 1e-3 and np.percentile(rel, 90) < 3e-3, (nv, np.median(rel), np.percentile(rel, 90))
+        assert np.median(ang) < 10.0 and np.median(made["ncc"]) > 0.9, (nv, np.median(ang), np.median(made["ncc"]))
+        e.close()
+
+
 def test_engine_schedule_is_as_good_as_the_reference_order():
     """The red-black / all-views-at-once ENGINE schedule against the FAITHFUL one (the reference's sequential raster sweep,
     live lists, minstd_rand0 draws): different patches, the same quality."""
