@@ -79,7 +79,11 @@ typedef struct mvs_config {
     int32_t view_propagation;/* 1 = also run the view-propagation branch the reference keeps commented out (propagate.cpp:110-120) */
     int32_t shard_index;     /* shard_count > 1: this engine sweeps the shard_index-th of shard_count equal, contiguous */
     int32_t shard_count;     /*   ranges of the (view, cell) sequence instead of whole views (view_begin/view_stride ignored) */
-    int64_t max_patches;     /* patch pool capacity (0 = 4 * total cells, at most a sixth of the free device memory per pool buffer) */
+    int32_t literal_groups;  /* Filter::filterSmallGroups: 0 = groups are the connected components of the symmetrised neighbour relation
+                              * (one pass of a union-find; default), 1 = the reference's breadth-first labelling in patch order over the
+                              * directed relation (filter.cpp:432-524), exactly: two passes and a small search on the host.
+                              * (Sits in what was padding before max_patches: sizeof(mvs_config) is unchanged.) */
+    int64_t max_patches;     /* patch pool capacity (0 = 4 * total cells, at most a sixth of the device's memory per pool buffer) */
 } mvs_config;
 
 /* One view: PhotoSet::m_photos[i] (image/photoSet.hpp:62).  P is the row-major 3x4 level-0 projection

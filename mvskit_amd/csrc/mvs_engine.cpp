@@ -145,6 +145,7 @@ struct mvs_engine {
     DevBuf<CellEntry> fat, vfat;
     DevBuf<int32_t> id32, vid32;  // the ids of fat / vfat alone
     DevBuf<int32_t> uf_parent, uf_size;  // Filter::filterSmallGroups union-find
+    DevBuf<int32_t> group_edges;         // its literal labelling: (root, root) pairs of the one-way edges between sets
     DevBuf<int32_t> cnt_alive, vcnt_alive;
     DevBuf<unsigned long long> dpgrid, best;
     bool index_valid = false;
@@ -388,6 +389,66 @@ int filter_exchange(mvs_engine* e, bool kills, bool records) {
     if (first_err != ncclSuccess) { g_err = std::string("Filter::run exchange: ") + R.GetErrorString(first_err); return MVS_ERR_HIP; }
     return MVS_OK;
 }
+// Filter::filterSmallGroups with the reference's own labelling (filter.cpp:432-524; mvs_config.literal_groups): a breadth-first search
+// in patch order over the DIRECTED relation "q is listed in the 3x3 cells around p in p's reference view and isNeighbor(p, q)" -- the
+// first unlabelled patch claims everything it reaches.  On the GPU: (1) the sets joined by edges that run BOTH ways (union-find;
+// inside such a set everything reaches everything, so the search claims a set whole or not at all, and the first unlabelled patch
+// is always the smallest index of its set = its root); (2) the edges that are left between different sets, as (root, root) pairs --
+// a few thousand; (3) on the host, the search over that condensed graph, sets in the order of their roots; (4) the size of its
+// literal group written over every set's size, and the removal as usual.
+int literal_small_groups(mvs_engine* e, int threshold) {
+    hipStream_t st = e->stream;
+    const DParams p = current_params(e);
+    const int cap = 8 << 20;  // (root, root) pairs
+    if (int r = e->group_edges.ensure(2 * (int64_t)cap)) return r;
+    int32_t* nedges = reinterpret_cast<int32_t*>(e->misc.p + 7);
+    HIPCHK(hipMemsetAsync(nedges, 0, sizeof(unsigned long long), st));
+    mvsk_groups_literal_edges(p, e->uf_parent.p, e->uf_size.p, e->group_edges.p, nedges, cap, st);
+    int32_t ne = 0;
+    HIPCHK(hipMemcpyAsync(&ne, nedges, sizeof ne, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if (ne > cap) { g_err = "Filter::filterSmallGroups (literal labelling): more than 8 M one-way edges between sets"; return MVS_ERR_CAPACITY; }
+    if (ne > 0) {
+        std::vector<int32_t> pairs(2 * (size_t)ne);
+        HIPCHK(hipMemcpy(pairs.data(), e->group_edges.p, pairs.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        // the sets that have such an edge, in the order of their roots
+        std::vector<int32_t> nodes(pairs);
+        std::sort(nodes.begin(), nodes.end());
+        nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+        const size_t nn = nodes.size();
+        auto idx = [&](int32_t root) { return (size_t)(std::lower_bound(nodes.begin(), nodes.end(), root) - nodes.begin()); };
+        std::vector<int32_t> sizes(nn);
+        if (int r = e->tmp_i.ensure((int64_t)2 * nn + 16)) return r;
+        HIPCHK(hipMemcpy(e->tmp_i.p, nodes.data(), nn * sizeof(int32_t), hipMemcpyHostToDevice));
+        mvsk_gather_i32(e->uf_size.p, e->tmp_i.p, e->tmp_i.p + nn, (int64_t)nn, st);
+        HIPCHK(hipMemcpyAsync(sizes.data(), e->tmp_i.p + nn, nn * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<std::vector<uint32_t>> adj(nn);
+        for (int32_t k = 0; k < ne; ++k) adj[idx(pairs[2 * k])].push_back((uint32_t)idx(pairs[2 * k + 1]));
+        std::vector<int32_t> label(nn, -1), gsize;
+        std::vector<uint32_t> queue;
+        for (size_t r0 = 0; r0 < nn; ++r0) {  // ascending roots = ascending first patches
+            if (label[r0] != -1) continue;
+            const int32_t gid = (int32_t)gsize.size();
+            int64_t total = 0;
+            queue.assign(1, (uint32_t)r0);
+            label[r0] = gid;
+            for (size_t qh = 0; qh < queue.size(); ++qh) {
+                const uint32_t u = queue[qh];
+                total += sizes[u];
+                for (uint32_t v : adj[u]) if (label[v] == -1) { label[v] = gid; queue.push_back(v); }
+            }
+            gsize.push_back((int32_t)std::min<int64_t>(total, INT32_MAX));
+        }
+        std::vector<int32_t> newsize(nn);
+        for (size_t u = 0; u < nn; ++u) newsize[u] = gsize[label[u]];
+        HIPCHK(hipMemcpy(e->tmp_i.p + nn, newsize.data(), nn * sizeof(int32_t), hipMemcpyHostToDevice));
+        mvsk_scatter_i32(e->uf_size.p, e->tmp_i.p, e->tmp_i.p + nn, (int64_t)nn, st);
+    }
+    mvsk_groups_kill(p, e->uf_parent.p, e->uf_size.p, threshold, e->kill.p, st);
+    return MVS_OK;
+}
 int filter_rebuild(mvs_engine* e, int additive, bool need_pgrid, bool need_vpgrid) {
     if (need_pgrid) { if (int r = build_list(e, false, false)) return r; }
     if (int r = build_depth(e)) return r;
@@ -525,7 +586,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     free_views(e);
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
-    e->uf_parent.release(); e->uf_size.release();
+    e->uf_parent.release(); e->uf_size.release(); e->group_edges.release();
     e->vcursor.release(); e->vids.release(); e->fat.release(); e->vfat.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
@@ -1193,7 +1254,8 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         if (e->uf_parent.ensure(e->pool.cap) || e->uf_size.ensure(e->pool.cap)) return MVS_ERR_HIP;
         const int threshold = (int)std::max<int64_t>(20, alive / 10000);
         HIPCHK(hipEventRecord(e->fev[6], st));
-        mvsk_groups(current_params(e), e->uf_parent.p, e->uf_size.p, threshold, e->kill.p, st);
+        if (!e->cfg.literal_groups) mvsk_groups(current_params(e), e->uf_parent.p, e->uf_size.p, threshold, e->kill.p, st);
+        else if (int r = literal_small_groups(e, threshold)) return r;
         HIPCHK(hipEventRecord(e->fev[7], st));
         if (int r = apply_kills(e, &rem[3])) return r;
     }

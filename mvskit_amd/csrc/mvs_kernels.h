@@ -37,4 +37,8 @@ void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* ev
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, int64_t first, int64_t last, hipStream_t st);
 void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* overflow, unsigned long long* stats, hipStream_t st);
 void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st);
+void mvsk_groups_literal_edges(const DParams& prm, int* parent, int* size, int* edges2, int* nedges, int cap, hipStream_t st);
+void mvsk_gather_i32(const int32_t* src, const int32_t* idx, int32_t* out, int64_t n, hipStream_t st);
+void mvsk_scatter_i32(int32_t* dst, const int32_t* idx, const int32_t* val, int64_t n, hipStream_t st);
+void mvsk_groups_kill(const DParams& prm, const int* parent, const int* size, int threshold, uint8_t* kill, hipStream_t st);
 void mvsk_probe(const DParams& prm, int op, int64_t n, const DPatch* in, const float* in_f, DPatch* out, float* out_f, int32_t* out_i, hipStream_t st);

@@ -839,13 +839,25 @@ __global__ void k_groups_init(int* parent, int* size, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { parent[i] = (int)i; size[i] = 0; }
 }
-__global__ void k_groups_union(DParams prm, int* parent) {
+// The relation of Filter::filterSmallGroups: q hangs on p when q is listed (m_pgrids or m_vpgrids) in the 3x3 cells around p in p's
+// reference view and isNeighbor(p, q).  MODE 0: every edge joins its two ends (connected components of the symmetrised relation).
+// MODE 1 (first pass of the literal labelling): only an edge whose reverse exists too joins them -- q -> p exists iff p is listed in
+// q's reference view w (w in p's m_images or m_vimages, p's cell there inside the grid) within one cell of q's own cell; isNeighbor is
+// symmetric.  MODE 2 (second pass): the edges that still run between two different sets, as (root of p, root of q) pairs.
+template <int MODE>
+__global__ void k_groups_edges(DParams prm, int* parent, int2* edges, int* nedges, int cap) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= prm.pool_n) return;
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
     const PGeo me = load_geo(p);
     const DView* vw = prm.views + me.ref;
+    unsigned long long listed = 0ull;  // the views p is listed in
+    if (MODE == 1) {
+        for (int i = 0; i < min(p->nimages, MVS_LISTCAP); ++i) listed |= 1ull << p->images[i];
+        for (int i = 0; i < min(p->nvimages, MVS_LISTCAP); ++i) listed |= 1ull << p->vimages[i];
+    }
+    int myroot = -1;
     int gx, gy;
     cell_of(prm, vw, me.coord, gx, gy);
     for (int y = -1; y <= 1; ++y) {
@@ -862,7 +874,24 @@ __global__ void k_groups_union(DParams prm, int* parent) {
                     const CellEntry e = fe[j];
                     if (e.id == (int)id) continue;
                     const PGeo q{{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
-                    if (is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) uf_union(parent, (int)id, e.id);
+                    if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) continue;
+                    if (MODE == 0) uf_union(parent, (int)id, e.id);
+                    else if (MODE == 1) {
+                        if (!((listed >> e.ref) & 1ull)) continue;
+                        const DView* qw = prm.views + e.ref;
+                        int px, py, qx, qy;
+                        cell_of(prm, qw, me.coord, px, py);
+                        cell_of(prm, qw, q.coord, qx, qy);
+                        if (px < 0 || qw->gw <= px || py < 0 || qw->gh <= py) continue;
+                        if (abs(px - qx) <= 1 && abs(py - qy) <= 1) uf_union(parent, (int)id, e.id);
+                    } else {
+                        if (myroot < 0) myroot = uf_find(parent, (int)id);
+                        const int rq = uf_find(parent, e.id);
+                        if (rq != myroot) {
+                            const int k = atomicAdd(nedges, 1);
+                            if (k < cap) edges[k] = make_int2(myroot, rq);
+                        }
+                    }
                 }
             }
         }
@@ -1065,9 +1094,31 @@ void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t
 void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st) {
     if (prm.pool_n <= 0) return;
     hipLaunchKernelGGL(k_groups_init, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, parent, size, prm.pool_n);
-    hipLaunchKernelGGL(k_groups_union, dim3(nblk(prm.pool_n, 128)), dim3(128), 0, st, prm, parent);
+    hipLaunchKernelGGL(k_groups_edges<0>, dim3(nblk(prm.pool_n, 128)), dim3(128), 0, st, prm, parent, (int2*)nullptr, (int*)nullptr, 0);
     hipLaunchKernelGGL(k_groups_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size);
     hipLaunchKernelGGL(k_groups_kill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size, threshold, kill);
+}
+// the literal labelling in three steps (mvs_engine.cpp does the middle one on the host): sets joined by edges that run both ways and
+// the edges left between different sets; then, with the sizes of the literal groups written over the sets' sizes, the removal
+void mvsk_groups_literal_edges(const DParams& prm, int* parent, int* size, int* edges2, int* nedges, int cap, hipStream_t st) {
+    if (prm.pool_n <= 0) return;
+    hipLaunchKernelGGL(k_groups_init, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, parent, size, prm.pool_n);
+    hipLaunchKernelGGL(k_groups_edges<1>, dim3(nblk(prm.pool_n, 128)), dim3(128), 0, st, prm, parent, (int2*)nullptr, (int*)nullptr, 0);
+    hipLaunchKernelGGL(k_groups_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size);  // also flattens parent[] to the roots
+    hipLaunchKernelGGL(k_groups_edges<2>, dim3(nblk(prm.pool_n, 128)), dim3(128), 0, st, prm, parent, reinterpret_cast<int2*>(edges2), nedges, cap);
+}
+__global__ void k_gather_i32(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int32_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+__global__ void k_scatter_i32(int32_t* __restrict__ dst, const int32_t* __restrict__ idx, const int32_t* __restrict__ val, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = val[i];
+}
+void mvsk_gather_i32(const int32_t* src, const int32_t* idx, int32_t* out, int64_t n, hipStream_t st) { if (n > 0) hipLaunchKernelGGL(k_gather_i32, dim3(nblk(n, 256)), dim3(256), 0, st, src, idx, out, n); }
+void mvsk_scatter_i32(int32_t* dst, const int32_t* idx, const int32_t* val, int64_t n, hipStream_t st) { if (n > 0) hipLaunchKernelGGL(k_scatter_i32, dim3(nblk(n, 256)), dim3(256), 0, st, dst, idx, val, n); }
+void mvsk_groups_kill(const DParams& prm, const int* parent, const int* size, int threshold, uint8_t* kill, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_groups_kill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size, threshold, kill);
 }
 void mvsk_probe(const DParams& prm, int op, int64_t n, const DPatch* in, const float* in_f, DPatch* out, float* out_f, int32_t* out_i, hipStream_t st) {
     if (n > 0 && op == 2) { hipLaunchKernelGGL(k_probe_refine, dim3((unsigned)n), dim3(64), MVS_FRAME_LDS_BYTES, st, prm, n, in, out); return; }

@@ -34,7 +34,7 @@ class Config(C.Structure):
                 ("seed", C.c_uint32), ("refine_steps", C.c_int32), ("refine_rd0", C.c_float), ("refine_ra0", C.c_float),
                 ("enable_check", C.c_int32), ("view_begin", C.c_int32), ("view_stride", C.c_int32),
                 ("device", C.c_int32), ("view_propagation", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
-                ("max_patches", C.c_int64)]
+                ("literal_groups", C.c_int32), ("max_patches", C.c_int64)]
 
 
 class ViewDesc(C.Structure):

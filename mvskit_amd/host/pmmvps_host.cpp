@@ -603,7 +603,7 @@ int PmMvps::createEngine(float maxAngle, float quad) {
     cfg.nviews = m_nimages; cfg.level = m_level; cfg.csize = m_csize; cfg.wsize = m_wsize;
     cfg.minImageNum = m_minImageNumThreshold; cfg.nccThreshold = m_nccThreshold;
     cfg.maxAngleThreshold = maxAngle; cfg.quadThreshold = quad;
-    cfg.depth = 0; cfg.seed = m_seed; cfg.refine_steps = m_refineSteps; cfg.view_propagation = m_viewPropagation;
+    cfg.depth = 0; cfg.seed = m_seed; cfg.refine_steps = m_refineSteps; cfg.view_propagation = m_viewPropagation; cfg.literal_groups = m_literalGroups;
     cfg.enable_check = 1;  // Optim::check from m_depth >= 2 (optim.cpp:292)
     cfg.device = m_device;
     if (m_world > 1 || !m_commIdFile.empty()) { cfg.shard_index = m_rank; cfg.shard_count = m_world; }

@@ -238,6 +238,7 @@ public:
     unsigned m_seed = 1;
     int m_refineSteps = 6;
     int m_viewPropagation = 0;  // 1 = the branch propagate.cpp:110-120 keeps commented out
+    int m_literalGroups = 0;    // 1 = Filter::filterSmallGroups labels breadth-first in patch order, as filter.cpp:432-524 does
     bool m_writeFiles = true;
 
     void updateThreshold();  // pmmvps.cpp:70-74

@@ -1472,7 +1472,7 @@ int filter_small_groups(Scene& s, int mode = 0, std::vector<int>* dead_out = nul
     if (psize == 0) return 0;
     std::vector<int> label(s.pool.size(), -1);
     int ngroups = 0;
-    const bool literal = mode == 1 || (mode == 0 && s.cfg.schedule == ORC_SCHEDULE_FAITHFUL);
+    const bool literal = mode == 1 || (mode == 0 && (s.cfg.schedule == ORC_SCHEDULE_FAITHFUL || s.cfg.literal_groups));
     if (literal) {
         for (int root : alive) {
             if (label[root] != -1) continue;

@@ -78,6 +78,8 @@ typedef struct orc_config {
                             * (propagate.cpp:235), refinePatch's own final computeINCC (optim.cpp:541) and the second
                             * constraintImages of postProcess (optim.cpp:286) are always evaluated, as the reference does.
                             * The patches must come out identical; only the work counters (evals, view_evals) differ. */
+    int32_t literal_groups; /* engine schedule only, 1 = Filter::filterSmallGroups labels as the FAITHFUL schedule does (breadth-first
+                             * in patch order, filter.cpp:432-524) instead of by connected components: mvs_config.literal_groups */
 } orc_config;
 
 typedef struct orc_counters {

@@ -54,7 +54,7 @@ class Config(C.Structure):
                 ("refine_rd0", C.c_float), ("refine_ra0", C.c_float), ("enable_check", C.c_int32),
                 ("view_begin", C.c_int32), ("view_stride", C.c_int32), ("nthreads", C.c_int32),
                 ("view_propagation", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
-                ("list_cap", C.c_int32), ("literal_evals", C.c_int32)]
+                ("list_cap", C.c_int32), ("literal_evals", C.c_int32), ("literal_groups", C.c_int32)]
 
 
 class Counters(C.Structure):

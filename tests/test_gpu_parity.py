@@ -425,6 +425,38 @@ def test_filter_run_matches_oracle(small_multi_scene):
         e.update_threshold()
 
 
+def test_filter_small_groups_literal_labelling():
+    """mvs_config.literal_groups: Filter::filterSmallGroups with the reference's own breadth-first labelling in patch order over the
+    directed relation (filter.cpp:432-524) instead of the connected components.  The GPU finds the sets joined by two-way edges and the
+    one-way edges left between them, the host walks those few sets in the order of their first patches; the oracle runs the literal
+    search patch by patch.  Same scene as tests/test_oracle_kat.py::test_small_groups_components_vs_literal_labelling, where the two
+    labellings remove different patches: removal counts and surviving patches equal the literal oracle's in all three Filter::run
+    calls, and differ from the default mode's at least once."""
+    sc = synth.make_scene(nviews=5, W=256, H=160, arc_deg=60.0, radius=4.0, kind="multi")
+    seeds = synth.make_seeds(sc, stride=3, seed=19)
+    o, e = _pair(sc, seed=21, enable_check=1, literal_groups=1)
+    o1, _ = _pair(sc, seed=21, enable_check=1)
+    for x in (o, e, o1):
+        (x.add_patches if x is not e else x.upload_patches)(seeds)
+    differs = 0
+    for it in range(3):
+        co, ce = o.propagate(it), e.propagate(it)
+        assert co == ce, (it, co, ce)
+        o1.propagate(it)
+        fo, fe, f1 = o.filter(), e.filter(), o1.filter()
+        assert fo == fe, (it, fo, fe)
+        differs += fo["groups"] != f1["groups"]
+        po, pe = o.patches(), e.patches()
+        assert po.shape == pe.shape
+        np.testing.assert_array_equal(po["images"], pe["images"])
+        np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+        for x in (o, e, o1):
+            x.update_threshold()
+    assert differs > 0
+    for x in (o, e, o1):
+        x.close()
+
+
 def _dense_pool(sc, per_cell, window=12, ref=0):
     """`per_cell` patches in every cell of a `window` x `window` block of view `ref`'s grid (make_seeds' noisy plane seeds, one
     draw per RNG seed), scored and scaled by hand: what Filter::run meets after a few iterations without the trim."""
