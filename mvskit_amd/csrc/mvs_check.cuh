@@ -211,7 +211,8 @@ DEV bool set_insert_from(int* table, unsigned mask, int k, unsigned p) {
     }
     return false;
 }
-template <int HCAP, bool G = false>
+#define MVS_FN_INFLIGHT 4  // id loads in flight in the row walk (8, 16, 32 measured the same or slower)
+template <int HCAP, bool G = false, bool ROWS = false /* the index has no gaps (built without the trim): walk it by grid rows */>
 DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin,
                        unsigned* stats = nullptr) {
     const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
@@ -248,41 +249,107 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     const int ntask = c.nimg * per;
     bool full = false;
     unsigned n_entries = 0;
-    for (int t0 = 0; t0 < ntask; t0 += 64) {
-        const int t = t0 + wc.lane;
-        const int i = min(t / per, c.nimg - 1), r = t % per;
-        const int v = __shfl(c.img, i), gx = __shfl(c.gx, i), gy = __shfl(c.gy, i);  // all lanes take part in the shuffles
-        if (t < ntask) {
-            const DView* vw = prm.views + v;
-            const int yt = gy + r / side - margin, xt = gx + r % side - margin;
-            if (!(yt < 0 || vw->gh <= yt || xt < 0 || vw->gw <= xt)) {
-                const int cell = yt * vw->gw + xt;
-                for (int kind = 0; kind < 2; ++kind) {
-                    const ListRef l = cell_span(prm, cx, kind, v, cell);
-                    n_entries += (unsigned)l.n;
-                    for (int j0 = 0; j0 < l.n; j0 += 4) {
-                        int id[4];
+    // the ids of a list from entry j_from on, four at a time: the first probe of the four keys together (four LDS atomics in
+    // flight): most keys are duplicates of one already in the set or find their slot empty, and are done here; the rest walk on
+    // one by one.  The final layout does not depend on the order of the insertions.
+    auto walk = [&](const ListRef& l, int j_from) {
+        for (int j0 = j_from; j0 < l.n; j0 += 4) {
+            int id[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int j = min(j0 + q, l.n - 1);
-                            id[q] = l.live ? cx.live_ids[j] : l.ids[j];
-                        }
-                        // first probe of the four keys together (four LDS atomics in flight): most keys are duplicates of
-                        // one already in the set or find their slot empty, and are done here; the rest walk on one by one.
-                        // The final layout does not depend on the order of the insertions.
-                        unsigned slot[4];
-                        int old[4];
+            for (int q = 0; q < 4; ++q) {
+                const int j = min(j0 + q, l.n - 1);
+                id[q] = l.live ? cx.live_ids[j] : l.ids[j];
+            }
+            unsigned slot[4];
+            int old[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            slot[q] = set_home<HCAP>(id[q]);
-                            old[q] = (j0 + q < l.n) ? atomicMax(&table[slot[q]], id[q]) : id[q];
-                        }
+            for (int q = 0; q < 4; ++q) {
+                slot[q] = set_home<HCAP>(id[q]);
+                old[q] = (j0 + q < l.n) ? atomicMax(&table[slot[q]], id[q]) : id[q];
+            }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (old[q] == id[q] || old[q] == MVS_SET_EMPTY) continue;
-                            const int carry = old[q] < id[q] ? old[q] : id[q];  // took the slot of a smaller key: carry that one on
-                            if (!set_insert_from(table, HCAP - 1, carry, (slot[q] + 1) & (HCAP - 1))) full = true;
-                        }
+            for (int q = 0; q < 4; ++q) {
+                if (old[q] == id[q] || old[q] == MVS_SET_EMPTY) continue;
+                const int carry = old[q] < id[q] ? old[q] : id[q];  // took the slot of a smaller key: carry that one on
+                if (!set_insert_from(table, HCAP - 1, carry, (slot[q] + 1) & (HCAP - 1))) full = true;
+            }
+        }
+    };
+    if (!ROWS) {
+        for (int t0 = 0; t0 < ntask; t0 += 64) {
+            const int t = t0 + wc.lane;
+            const int i = min(t / per, c.nimg - 1), r = t % per;
+            const int v = __shfl(c.img, i), gx = __shfl(c.gx, i), gy = __shfl(c.gy, i);  // all lanes take part in the shuffles
+            if (t < ntask) {
+                const DView* vw = prm.views + v;
+                const int yt = gy + r / side - margin, xt = gx + r % side - margin;
+                if (!(yt < 0 || vw->gh <= yt || xt < 0 || vw->gw <= xt)) {
+                    const int cell = yt * vw->gw + xt;
+                    for (int kind = 0; kind < 2; ++kind) {
+                        const ListRef l = cell_span(prm, cx, kind, v, cell);
+                        n_entries += (unsigned)l.n;
+                        walk(l, 0);
+                    }
+                }
+            }
+        }
+    } else {
+        // Filter::filterNeighbor (a wave per patch).  Its indexes are built without the trim (Filter::setDepthMapsVGridsVPGridsAddPatchV),
+        // so the lists of neighbouring cells lie end to end: the (2 margin + 1) cells of a grid row are ONE run of ids.  A lane per row
+        // (view, kind, dy) fetches its run, the runs are laid end to end and the lanes take consecutive ids (the run of an id: a binary
+        // search over the running totals, which sit in the lanes): 64 useful ids per load and per round of LDS atomics, where the
+        // lane-per-list walk above runs as long as the longest list of 64.  The kernel is bound by instruction issue (vector ALU busy
+        // 86 % of the time, profiles/r03_pmc_filter_kernels.json), so what counts is instructions per id; a row per step with its
+        // start in scalar registers needs fewer per load but twice the rounds of atomics, and measured slower (67.6 against 61.6 ms).
+        // The final layout does not depend on the order of the insertions.
+        const int nrow = 2 * side * __builtin_amdgcn_readfirstlane(c.nimg);
+        for (int r0 = 0; r0 < nrow; r0 += 64) {
+            const int r = r0 + wc.lane, rc = min(r, nrow - 1);
+            const int i = rc / (2 * side), dy = rc % side - margin;
+            const bool vk = ((rc / side) & 1) != 0;
+            const int v = __shfl(c.img, i), gx = __shfl(c.gx, i), gy = __shfl(c.gy, i);
+            int b = 0, len = 0;
+            if (r < nrow) {
+                const DView* vw = prm.views + v;
+                const int yt = gy + dy, x0 = max(gx - margin, 0), x1 = min(gx + margin, vw->gw - 1);
+                if (0 <= yt && yt < vw->gh && x0 <= x1) {
+                    const int32_t* st = vk ? prm.vcsr_start : prm.csr_start;
+                    const int g0 = vw->cell_base + yt * vw->gw + x0;
+                    b = st[g0];
+                    len = st[g0 + (x1 - x0) + 1] - b;
+                }
+            }
+            int P = len;  // the running total over the lanes: inclusive, then exclusive
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(P, d); if (wc.lane >= d) P += o; }
+            const int total = __builtin_amdgcn_readlane(P, 63);
+            P -= len;
+            if (wc.lane == 0) n_entries += (unsigned)total;
+            for (int k0 = 0; k0 < total; k0 += 64 * MVS_FN_INFLIGHT) {
+                int id[MVS_FN_INFLIGHT];
+#pragma unroll
+                for (int u = 0; u < MVS_FN_INFLIGHT; ++u) {
+                    const int k = k0 + 64 * u + wc.lane;
+                    int lo = 0;  // the run id k falls in: the last lane whose run begins at or before k
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) { const int pc = __shfl(P, lo + step); if (pc <= k) lo += step; }
+                    const int bb = __shfl(b, lo), pl = __shfl(P, lo);
+                    const bool kv = (((r0 + lo) / side) & 1) != 0;
+                    id[u] = k < total ? (kv ? prm.vcsr_id32 : prm.csr_id32)[bb + (k - pl)] : MVS_SET_EMPTY;
+                }
+#pragma unroll
+                for (int u0 = 0; u0 < MVS_FN_INFLIGHT; u0 += 4) {
+                    if (k0 + 64 * u0 >= total) break;
+                    unsigned slot[4];
+                    int old[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        slot[u] = set_home<HCAP>(id[u0 + u]);
+                        old[u] = id[u0 + u] != MVS_SET_EMPTY ? atomicMax(&table[slot[u]], id[u0 + u]) : id[u0 + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (old[u] == id[u0 + u] || old[u] == MVS_SET_EMPTY) continue;
+                        if (!set_insert_from(table, HCAP - 1, old[u] < id[u0 + u] ? old[u] : id[u0 + u], (slot[u] + 1) & (HCAP - 1))) full = true;
                     }
                 }
             }

@@ -149,6 +149,7 @@ struct mvs_engine {
     DevBuf<int32_t> cnt_alive, vcnt_alive;
     DevBuf<unsigned long long> dpgrid, best;
     bool index_valid = false;
+    bool lists_dense[2] = {false, false};  // m_pgrids / m_vpgrids index built without the trim: the lists of neighbouring cells lie end to end
     // sweep / staging
     DevBuf<DPatch> staging;
     DevBuf<int32_t> job_stage, job_nstage, job_cnt, job_base_scan, kill_cnt, kill_base, per_view;
@@ -325,6 +326,7 @@ int build_list(mvs_engine* e, bool vgrid, bool trim) {
                     vgrid ? cursor.p : nullptr, vgrid ? ids.p : nullptr, st);
     mvsk_index_sort_trim(p, start.p, ids.p, trim ? 1 : 0, e->misc.p + 3, st);
     mvsk_index_finalize(p, start.p, ids.p, fat.p, id32.p, cnt_alive.p, st);
+    e->lists_dense[vgrid ? 1 : 0] = !trim;
     return MVS_OK;
 }
 int build_depth(mvs_engine* e) {  // m_dpgrids from the alive pool
@@ -1234,6 +1236,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         HIPCHK(hipMemsetAsync(e->misc.p + 4, 0, sizeof(unsigned long long), st));
         int32_t* nretry = reinterpret_cast<int32_t*>(e->misc.p + 4);
         HIPCHK(hipEventRecord(e->fev[4], st));
+        if (!e->lists_dense[0] || !e->lists_dense[1]) { g_err = "Filter::filterNeighbor: the grid indexes must come from a rebuild without the trim"; return MVS_ERR_ARG; }
         filter_range(e, first, last);
         mvsk_filter_neighbor(current_params(e), e->kill.p, e->uf_parent.p, nretry, e->error_flag.p, e->fstat_buf.p, first, last, st);
         int32_t nr = 0;

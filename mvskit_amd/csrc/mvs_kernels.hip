@@ -215,27 +215,30 @@ __global__ void k_index_finalize(DParams prm, const int32_t* __restrict__ start,
     cnt_alive[g] = n;
 }
 // PatchManager::updateDepthMaps, patch_manager.cpp:191-221, over the alive pool (Filter::setDepthMaps, filter.cpp:580-626)
-__global__ void k_depth_maps(DParams prm, unsigned long long* __restrict__ dp) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t id = t / prm.nviews;
-    const int image = (int)(t % prm.nviews);
+// A lane per patch, a wave per view (the four waves of a block share 64 consecutive patches and take the views in turn): patches that
+// follow each other in the pool lie next to each other on the surface, so the 64 cells a wave touches in one view's map share
+// cache lines -- with a lane per (patch, view) pair every lane of a wave wrote into another view's map.
+__global__ __launch_bounds__(256) void k_depth_maps(DParams prm, unsigned long long* __restrict__ dp) {
+    const int64_t id = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63u);
     if (id >= prm.pool_n) return;
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
     const F4 coord = ld4(p->coord);
-    const DView* vw = prm.views + image;
-    const F3 ic = project(vw, coord, prm.level);
-    const float fx = ic.x / (float)prm.csize, fy = ic.y / (float)prm.csize;
-    const int xs[2] = {(int)floorf(fx), (int)ceilf(fx)}, ys[2] = {(int)floorf(fy), (int)ceilf(fy)};
-    const float depth = dot4(ld4(vw->oaxis), coord);
-    const unsigned long long key = ((unsigned long long)sortable_f32(depth) << 32) | (unsigned long long)(uint32_t)id;
-    for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) {
-        if (xs[i] < 0 || vw->gw <= xs[i] || ys[j] < 0 || vw->gh <= ys[j]) continue;
-        if (i == 1 && xs[1] == xs[0]) continue;  // same cell twice: idempotent, skip
-        if (j == 1 && ys[1] == ys[0]) continue;
-        // the cell's value only ever decreases: a plain read that already shows a nearer patch saves the atomic (most do)
-        unsigned long long* cellp = &dp[vw->cell_base + ys[j] * vw->gw + xs[i]];
-        if (key < __builtin_nontemporal_load(cellp)) atomicMin(cellp, key);
+    for (int image = (int)(threadIdx.x >> 6); image < prm.nviews; image += 4) {
+        const DView* vw = prm.views + image;
+        const F3 ic = project(vw, coord, prm.level);
+        const float fx = ic.x / (float)prm.csize, fy = ic.y / (float)prm.csize;
+        const int xs[2] = {(int)floorf(fx), (int)ceilf(fx)}, ys[2] = {(int)floorf(fy), (int)ceilf(fy)};
+        const float depth = dot4(ld4(vw->oaxis), coord);
+        const unsigned long long key = ((unsigned long long)sortable_f32(depth) << 32) | (unsigned long long)(uint32_t)id;
+        for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) {
+            if (xs[i] < 0 || vw->gw <= xs[i] || ys[j] < 0 || vw->gh <= ys[j]) continue;
+            if (i == 1 && xs[1] == xs[0]) continue;  // same cell twice: idempotent, skip
+            if (j == 1 && ys[1] == ys[0]) continue;
+            // the cell's value only ever decreases: a plain read that already shows a nearer patch saves the atomic (most do)
+            unsigned long long* cellp = &dp[vw->cell_base + ys[j] * vw->gw + xs[i]];
+            if (key < __builtin_nontemporal_load(cellp)) atomicMin(cellp, key);
+        }
     }
 }
 // best-NCC patch per cell among those whose reference view is `view` (parity artefact)
@@ -803,7 +806,7 @@ __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* ki
     const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, nullptr};
     int* table = reinterpret_cast<int*>(s_lds);
     unsigned st4[4] = {0u, 0u, 0u, 0u};
-    const int n = find_neighbors<HCAP>(prm, wc, cx, c, table, 4.0f, 2, st4);
+    const int n = find_neighbors<HCAP, false, true>(prm, wc, cx, c, table, 4.0f, 2, st4);
     if (n < 0 || n > RCAP) {
         if (wc.lane == 0) {
             if (retry) retry[atomicAdd(nretry, 1)] = (int32_t)id;
@@ -844,9 +847,13 @@ __global__ void k_groups_init(int* parent, int* size, int64_t n) {
 // MODE 1 (first pass of the literal labelling): only an edge whose reverse exists too joins them -- q -> p exists iff p is listed in
 // q's reference view w (w in p's m_images or m_vimages, p's cell there inside the grid) within one cell of q's own cell; isNeighbor is
 // symmetric.  MODE 2 (second pass): the edges that still run between two different sets, as (root of p, root of q) pairs.
+// One wave per patch: the 18 lists (3x3 cells, m_pgrids and m_vpgrids) are laid end to end and the lanes take consecutive entries, so
+// a wave reads its 48-byte entries as contiguous runs (a lane per patch reads one cache line per lane and load, and 2048 lanes per
+// CU evict each other's lines between the three loads of an entry: 24 ms per call at 1080p against 3 for this form).
 template <int MODE>
-__global__ void k_groups_edges(DParams prm, int* parent, int2* edges, int* nedges, int cap) {
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, int2* edges, int* nedges, int cap) {
+    const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63u);
     if (id >= prm.pool_n) return;
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
@@ -857,42 +864,49 @@ __global__ void k_groups_edges(DParams prm, int* parent, int2* edges, int* nedge
         for (int i = 0; i < min(p->nimages, MVS_LISTCAP); ++i) listed |= 1ull << p->images[i];
         for (int i = 0; i < min(p->nvimages, MVS_LISTCAP); ++i) listed |= 1ull << p->vimages[i];
     }
-    int myroot = -1;
     int gx, gy;
     cell_of(prm, vw, me.coord, gx, gy);
-    for (int y = -1; y <= 1; ++y) {
-        const int yt = gy + y;
-        if (yt < 0 || vw->gh <= yt) continue;
-        for (int x = -1; x <= 1; ++x) {
-            const int xt = gx + x;
-            if (xt < 0 || vw->gw <= xt) continue;
+    // lane l < 18: list l = (kind, dy, dx); its start and length, and the running total before it
+    int lstart = 0, ln = 0;
+    if (lane < 18) {
+        const int kind = lane / 9, yt = gy + (lane % 9) / 3 - 1, xt = gx + lane % 3 - 1;
+        if (!(yt < 0 || vw->gh <= yt || xt < 0 || vw->gw <= xt)) {
             const int g = vw->cell_base + yt * vw->gw + xt;
-            for (int kind = 0; kind < 2; ++kind) {
-                const CellEntry* fe = kind == 0 ? prm.csr_fat + prm.csr_start[g] : prm.vcsr_fat + prm.vcsr_start[g];
-                const int n = kind == 0 ? prm.csr_cnt[g] : prm.vcsr_cnt[g];
-                for (int j = 0; j < n; ++j) {
-                    const CellEntry e = fe[j];
-                    if (e.id == (int)id) continue;
-                    const PGeo q{{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
-                    if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) continue;
-                    if (MODE == 0) uf_union(parent, (int)id, e.id);
-                    else if (MODE == 1) {
-                        if (!((listed >> e.ref) & 1ull)) continue;
-                        const DView* qw = prm.views + e.ref;
-                        int px, py, qx, qy;
-                        cell_of(prm, qw, me.coord, px, py);
-                        cell_of(prm, qw, q.coord, qx, qy);
-                        if (px < 0 || qw->gw <= px || py < 0 || qw->gh <= py) continue;
-                        if (abs(px - qx) <= 1 && abs(py - qy) <= 1) uf_union(parent, (int)id, e.id);
-                    } else {
-                        if (myroot < 0) myroot = uf_find(parent, (int)id);
-                        const int rq = uf_find(parent, e.id);
-                        if (rq != myroot) {
-                            const int k = atomicAdd(nedges, 1);
-                            if (k < cap) edges[k] = make_int2(myroot, rq);
-                        }
-                    }
-                }
+            lstart = kind == 0 ? prm.csr_start[g] : prm.vcsr_start[g];
+            ln = kind == 0 ? prm.csr_cnt[g] : prm.vcsr_cnt[g];
+        }
+    }
+    int before = ln;  // inclusive running total over the lanes, then exclusive
+    for (int d = 1; d < 32; d <<= 1) { const int o = __shfl_up(before, d); if (lane >= d) before += o; }
+    const int total = __builtin_amdgcn_readlane(before, 17);
+    before -= ln;
+    int myroot = -1;
+    for (int k0 = 0; k0 < total; k0 += 64) {
+        const int k = k0 + lane;
+        int lo = 0;  // the list entry k falls in: the last lane whose list begins at or before k (lanes 18.. hold the total; an empty list never wins)
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1) { const int pc = __shfl(before, lo + step); if (pc <= k) lo += step; }
+        const int l_first = __shfl(before, lo), l_start = __shfl(lstart, lo), l_kind = lo >= 9 ? 1 : 0;
+        if (k >= total) continue;
+        const CellEntry e = (l_kind == 0 ? prm.csr_fat : prm.vcsr_fat)[l_start + (k - l_first)];
+        if (e.id == (int)id) continue;
+        const PGeo q{{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
+        if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) continue;
+        if (MODE == 0) uf_union(parent, (int)id, e.id);
+        else if (MODE == 1) {
+            if (!((listed >> e.ref) & 1ull)) continue;
+            const DView* qw = prm.views + e.ref;
+            int px, py, qx, qy;
+            cell_of(prm, qw, me.coord, px, py);
+            cell_of(prm, qw, q.coord, qx, qy);
+            if (px < 0 || qw->gw <= px || py < 0 || qw->gh <= py) continue;
+            if (abs(px - qx) <= 1 && abs(py - qy) <= 1) uf_union(parent, (int)id, e.id);
+        } else {
+            if (myroot < 0) myroot = uf_find(parent, (int)id);
+            const int rq = uf_find(parent, e.id);
+            if (rq != myroot) {
+                const int k2 = atomicAdd(nedges, 1);
+                if (k2 < cap) edges[k2] = make_int2(myroot, rq);
             }
         }
     }
@@ -1003,8 +1017,7 @@ void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigne
     hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, fat, id32, cnt_alive);
 }
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, hipStream_t st) {
-    const int64_t n = prm.pool_n * prm.nviews;
-    if (n > 0) hipLaunchKernelGGL(k_depth_maps, dim3(nblk(n, 256)), dim3(256), 0, st, prm, dp);
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_depth_maps, dim3(nblk(prm.pool_n, 64)), dim3(256), 0, st, prm, dp);
 }
 void mvsk_best_ncc_map(const DParams& prm, int view, unsigned long long* best, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_best_ncc_map, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, view, best);
@@ -1094,7 +1107,7 @@ void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t
 void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint8_t* kill, hipStream_t st) {
     if (prm.pool_n <= 0) return;
     hipLaunchKernelGGL(k_groups_init, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, parent, size, prm.pool_n);
-    hipLaunchKernelGGL(k_groups_edges<0>, dim3(nblk(prm.pool_n, 128)), dim3(128), 0, st, prm, parent, (int2*)nullptr, (int*)nullptr, 0);
+    hipLaunchKernelGGL(k_groups_edges<0>, dim3(nblk(prm.pool_n, 4)), dim3(256), 0, st, prm, parent, (int2*)nullptr, (int*)nullptr, 0);
     hipLaunchKernelGGL(k_groups_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size);
     hipLaunchKernelGGL(k_groups_kill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size, threshold, kill);
 }
@@ -1103,9 +1116,9 @@ void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint
 void mvsk_groups_literal_edges(const DParams& prm, int* parent, int* size, int* edges2, int* nedges, int cap, hipStream_t st) {
     if (prm.pool_n <= 0) return;
     hipLaunchKernelGGL(k_groups_init, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, parent, size, prm.pool_n);
-    hipLaunchKernelGGL(k_groups_edges<1>, dim3(nblk(prm.pool_n, 128)), dim3(128), 0, st, prm, parent, (int2*)nullptr, (int*)nullptr, 0);
+    hipLaunchKernelGGL(k_groups_edges<1>, dim3(nblk(prm.pool_n, 4)), dim3(256), 0, st, prm, parent, (int2*)nullptr, (int*)nullptr, 0);
     hipLaunchKernelGGL(k_groups_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size);  // also flattens parent[] to the roots
-    hipLaunchKernelGGL(k_groups_edges<2>, dim3(nblk(prm.pool_n, 128)), dim3(128), 0, st, prm, parent, reinterpret_cast<int2*>(edges2), nedges, cap);
+    hipLaunchKernelGGL(k_groups_edges<2>, dim3(nblk(prm.pool_n, 4)), dim3(256), 0, st, prm, parent, reinterpret_cast<int2*>(edges2), nedges, cap);
 }
 __global__ void k_gather_i32(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int32_t* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
