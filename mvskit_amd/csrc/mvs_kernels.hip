@@ -660,17 +660,47 @@ DEV void store_lists(DPatch* p, const WaveCtx& wc, const Cand& c) {
 }
 // Filter::setVGridsVPGrids (filter.cpp:657-664): m_vimages cleared (additive == 0) or kept, then setVImagesVGrids
 // (all Filter::run kernels take a patch range [first, last): a rank of a multi-GPU job filters its share of the pool)
-__global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive, int64_t first) {
-    __shared__ int s_scratch[192];
-    DPatch* p = prm.pool + first + blockIdx.x;
-    if (!(p->flags & 1)) return;
-    WaveCtx wc = make_wave_ctx(prm);
-    Cand c;
-    load_cand(p, wc, c);
-    if (!additive) c.nvimg = 0;
-    set_vgrids(prm, wc, c);
-    set_vimages_vgrids(prm, wc, s_scratch, c);
-    store_lists(p, wc, c);
+// GL lanes per patch (a lane per view; GL >= the views and >= the list storage), 64 / GL patches per wave: with 12 views a wave per
+// patch leaves 52 lanes idle through the two dependent gathers of isVisible.
+template <int GL>
+__global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive, int64_t first, int64_t last) {
+    __shared__ int s_new[64];
+    const int lane = (int)threadIdx.x, g = lane / GL, i = lane % GL;
+    const int64_t id = first + (int64_t)blockIdx.x * (64 / GL) + g;
+    const bool have = id < last;
+    DPatch* p = prm.pool + (have ? id : first);
+    const bool act = have && (p->flags & 1);
+    const int nimg = act ? min(p->nimages, MVS_LISTCAP) : 0;
+    const int nv0 = act && additive ? min(p->nvimages, MVS_LISTCAP) : 0;
+    const int my_img = i < MVS_MAXI ? (int)p->images[i] : 0, my_vimg = i < MVS_MAXI ? (int)p->vimages[i] : 0;
+    // the views the patch is listed in, as a mask shared by the group
+    unsigned long long listed = (i < nimg ? 1ull << my_img : 0ull) | (i < nv0 ? 1ull << my_vimg : 0ull);
+#pragma unroll
+    for (int d = 1; d < GL; d <<= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)listed, d), hi = (unsigned)__shfl_xor((int)(unsigned)(listed >> 32), d);
+        listed |= ((unsigned long long)hi << 32) | lo;
+    }
+    bool q = false;
+    if (act && i < prm.nviews && !((listed >> i) & 1ull)) {
+        Cand c;
+        c.coord = ld4(p->coord); c.normal = ld4(p->normal);
+        int ix, iy;
+        cell_of(prm, prm.views + i, c.coord, ix, iy);
+        q = is_visible(prm, c, i, ix, iy, prm.neighborThreshold) != 0;
+    }
+    const unsigned long long all = __ballot(q);
+    const unsigned long long gm = GL == 64 ? all : (all >> (GL * g)) & ((1ull << (GL & 63)) - 1ull);
+    const int added = (int)__popcll(gm), pos = (int)__popcll(gm & ((1ull << i) - 1ull));
+    if (q) s_new[GL * g + pos] = i;  // the r-th view added, in ascending order
+    __syncthreads();
+    const int nv = min(MVS_LISTCAP, nv0 + added);
+    if (act) {
+        if (i == 0) { p->nimages = nimg; p->nvimages = nv; }
+        if (i < MVS_MAXI) {
+            p->images[i] = (uint8_t)(i < nimg ? my_img : 0);
+            p->vimages[i] = (uint8_t)(i < nv0 ? my_vimg : (i < nv ? s_new[GL * g + (i - nv0)] : 0));
+        }
+    }
 }
 // Filter::filterOutside, filter.cpp:51-106: gain < 0 -> removed
 __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kill, int64_t first) {
@@ -1086,7 +1116,12 @@ void mvsk_alive_gather(const DPatch* pool, int64_t n, const int32_t* base, DPatc
     if (n > 0) hipLaunchKernelGGL(k_alive_gather, dim3(nblk(n, 256)), dim3(256), 0, st, pool, n, base, out, cap);
 }
 void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_t last, hipStream_t st) {
-    if (last > first) hipLaunchKernelGGL(k_filter_vimages, dim3((unsigned)(last - first)), dim3(64), 0, st, prm, additive, first);
+    if (last <= first) return;
+    const int gl = std::max(prm.nviews <= 16 ? 16 : (prm.nviews <= 32 ? 32 : 64), (int)MVS_MAXI);
+    const unsigned nb = (unsigned)((last - first + 64 / gl - 1) / (64 / gl));
+    if (gl == 16) hipLaunchKernelGGL(k_filter_vimages<16>, dim3(nb), dim3(64), 0, st, prm, additive, first, last);
+    else if (gl == 32) hipLaunchKernelGGL(k_filter_vimages<32>, dim3(nb), dim3(64), 0, st, prm, additive, first, last);
+    else hipLaunchKernelGGL(k_filter_vimages<64>, dim3(nb), dim3(64), 0, st, prm, additive, first, last);
 }
 void mvsk_filter_outside(const DParams& prm, uint8_t* kill, int64_t first, int64_t last, hipStream_t st) {
     if (last > first) hipLaunchKernelGGL(k_filter_outside, dim3((unsigned)(last - first)), dim3(64), 0, st, prm, kill, first);
