@@ -293,7 +293,8 @@ bool want_vgrid(const mvs_engine* e) { return e->prm.depth >= 2 && e->prm.enable
 
 // One cell index (m_pgrids or m_vpgrids): count -> scan -> fill -> per-cell sort (ncc desc, id asc) [-> trim to
 // MAX_NUM_OF_PATCHES] -> compaction to alive entries, written out as fat CellEntry streams.
-int build_list(mvs_engine* e, bool vgrid, bool trim) {
+// `unordered` (the rebuilds inside Filter::run, never with the trim): the entries of a list in no particular order, see k_index_fill_direct
+int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
     hipStream_t st = e->stream;
     const int64_t nc = e->total_cells;
     DParams p = current_params(e);
@@ -317,11 +318,17 @@ int build_list(mvs_engine* e, bool vgrid, bool trim) {
         g_err = "cell index: more than 2^31 list entries (patches x views per patch); lower mvs_config.max_patches";
         return MVS_ERR_CAPACITY;
     }
-    if (int r = ids.ensure(tot + 16)) return r;
+    if (!unordered) { if (int r = ids.ensure(tot + 16)) return r; }
     if (int r = fat.ensure(tot + 16)) return r;
     if (int r = id32.ensure(tot + 16)) return r;
     p = current_params(e);
     HIPCHK(hipMemsetAsync(cursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
+    if (unordered && !trim) {
+        mvsk_index_fill_direct(p, vgrid ? 1 : 0, start.p, cursor.p, fat.p, id32.p, st);
+        HIPCHK(hipMemcpyAsync(cnt_alive.p, cnt.p, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        e->lists_dense[vgrid ? 1 : 0] = true;
+        return MVS_OK;
+    }
     mvsk_index_fill(p, vgrid ? nullptr : start.p, vgrid ? nullptr : cursor.p, vgrid ? nullptr : ids.p, vgrid ? start.p : nullptr,
                     vgrid ? cursor.p : nullptr, vgrid ? ids.p : nullptr, st);
     mvsk_index_sort_trim(p, start.p, ids.p, trim ? 1 : 0, e->misc.p + 3, st);
@@ -452,13 +459,13 @@ int literal_small_groups(mvs_engine* e, int threshold) {
     return MVS_OK;
 }
 int filter_rebuild(mvs_engine* e, int additive, bool need_pgrid, bool need_vpgrid) {
-    if (need_pgrid) { if (int r = build_list(e, false, false)) return r; }
+    if (need_pgrid) { if (int r = build_list(e, false, false, true)) return r; }
     if (int r = build_depth(e)) return r;
     int64_t first, last;
     filter_range(e, first, last);
     mvsk_filter_vimages(current_params(e), additive, first, last, e->stream);
     if (int r = filter_exchange(e, false, true)) return r;  // m_vimages of the other ranks' patches
-    if (need_vpgrid) { if (int r = build_list(e, true, false)) return r; }
+    if (need_vpgrid) { if (int r = build_list(e, true, false, true)) return r; }
     HIPCHK(hipGetLastError());
     return MVS_OK;
 }

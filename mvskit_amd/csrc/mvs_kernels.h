@@ -11,6 +11,7 @@ void mvsk_mask_binarise(uint8_t* m, int64_t n, hipStream_t st);
 void mvsk_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, hipStream_t st);
 void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, unsigned long long* total, hipStream_t st);
 void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, unsigned long long* ids, const int32_t* vstart, int32_t* vcursor, unsigned long long* vids, hipStream_t st);
+void mvsk_index_fill_direct(const DParams& prm, int vgrid, const int32_t* start, int32_t* cursor, CellEntry* fat, int32_t* id32, hipStream_t st);
 void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st);
 void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* id32, int32_t* cnt_alive, hipStream_t st);
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, hipStream_t st);

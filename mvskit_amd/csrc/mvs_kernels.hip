@@ -163,6 +163,33 @@ __global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int
         }
     }
 }
+// The index between the stages of Filter::run: no trim, and no stage depends on the order inside a list (computeGain takes maxima,
+// findNeighbors builds a set whose layout is the same for every insertion order, filterSmallGroups joins sets), so the thread that
+// holds the record writes the finished entry straight into its slot: no keys, no per-cell sort, no gather of the records.
+__global__ void k_index_fill_direct(DParams prm, int vgrid, const int32_t* __restrict__ start, int32_t* __restrict__ cursor, CellEntry* __restrict__ fat,
+                                    int32_t* __restrict__ id32) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= prm.pool_n) return;
+    const DPatch* p = prm.pool + id;
+    if (!(p->flags & 1)) return;
+    const F4 coord = ld4(p->coord), normal = ld4(p->normal);
+    CellEntry ce;
+    ce.id = (int32_t)id; ce.ncc = p->ncc;
+    ce.coord[0] = coord.x; ce.coord[1] = coord.y; ce.coord[2] = coord.z;
+    ce.normal[0] = normal.x; ce.normal[1] = normal.y; ce.normal[2] = normal.z;
+    ce.dscale = p->dscale; ce.ref = p->images[0]; ce.pad[0] = 0; ce.pad[1] = 0;
+    const int n = vgrid ? min(p->nvimages, MVS_LISTCAP) : min(p->nimages, MVS_LISTCAP);
+    for (int i = 0; i < n; ++i) {
+        const DView* vw = prm.views + (vgrid ? p->vimages[i] : p->images[i]);
+        int ix, iy;
+        cell_of(prm, vw, coord, ix, iy);
+        if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
+        const int g = vw->cell_base + iy * vw->gw + ix;
+        const int slot = start[g] + atomicAdd(&cursor[g], 1);
+        fat[slot] = ce;
+        id32[slot] = (int32_t)id;
+    }
+}
 // PatchManager::sortPatches (descending NCC; ties by id) per cell, then the MAX_NUM_OF_PATCHES trim
 // (propagate.cpp:94-99,130-135): every cell decides on the same snapshot; a trimmed patch dies everywhere.
 __global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start, unsigned long long* __restrict__ ids, int do_trim,
@@ -1039,6 +1066,9 @@ void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, unsigned 
 }
 void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, unsigned long long* ids, const int32_t* vstart, int32_t* vcursor, unsigned long long* vids, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, start, cursor, ids, vstart, vcursor, vids);
+}
+void mvsk_index_fill_direct(const DParams& prm, int vgrid, const int32_t* start, int32_t* cursor, CellEntry* fat, int32_t* id32, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill_direct, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, vgrid, start, cursor, fat, id32);
 }
 void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
     hipLaunchKernelGGL(k_index_sort_trim, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, do_trim, trimmed);
