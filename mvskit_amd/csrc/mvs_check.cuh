@@ -35,7 +35,7 @@ namespace mvsdev {
 #define MVS_SET_LDS_FLOATS(HCAP, RCAP) ((HCAP) > MVS_SET_ROWS_FLOATS(RCAP) ? (HCAP) : MVS_SET_ROWS_FLOATS(RCAP))
 static_assert(MVS_SET_LDS_FLOATS(MVS_HASH_CAP, MVS_ROW_CAP) <= MVS_CHECK_LDS_FLOATS, "neighbour search LDS");
 #define MVS_FILTER_HASH_CAP 2048           // Filter::filterNeighbor, first launch over all patches: the small configuration in both builds
-#define MVS_FILTER_ROW_CAP 576
+#define MVS_FILTER_ROW_CAP 448            // 448 + 3 * 448 + 64 floats of rows fit the 8 KB of the set: 20 waves per CU (at 576: 16)
 #define MVS_FILTER2_HASH_CAP 16384         // second launch over the patches the first could not hold: exactly 64 KB of dynamic LDS (the
 #define MVS_FILTER2_ROW_CAP 4064           // kernel has no static LDS), which also holds 4096 + 3 * 4064 + 64 dwords of ids, rows and sums
 static_assert(MVS_SET_LDS_FLOATS(MVS_FILTER2_HASH_CAP, MVS_FILTER2_ROW_CAP) * 4 <= 65536, "the retry launch of Filter::filterNeighbor asks for at most 64 KB");

@@ -1162,7 +1162,7 @@ void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* ev
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, int64_t first, int64_t last, hipStream_t st) {
     if (last <= first) return;
     hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP>), dim3((unsigned)(last - first)), dim3(64),
-                       (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow, stats, first);
+                       (size_t)MVS_SET_LDS_FLOATS(MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP) * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow, stats, first);
 }
 void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* overflow, unsigned long long* stats, hipStream_t st) {
     if (ntodo <= 0) return;

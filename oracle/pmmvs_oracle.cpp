@@ -1183,7 +1183,8 @@ float compute_radius(const Scene& s, const Patch& p) {
  * linear-probing table (each key sits behind larger keys only), whose layout does not depend on the order of the
  * insertions: it is the layout of inserting the keys in descending order with plain linear probing.  The accepted ids
  * are taken in slot order.  Table size: first_cap slots while at most 7/8 of them are visited and at most first_rows ids
- * are accepted (mvs_check.cuh: 2048 / 576 -- MVS_HASH_CAP, MVS_ROW_CAP; 4096 / 1152 in Optim::check of the 64-view build),
+ * are accepted (mvs_check.cuh: 2048 / 576 -- MVS_HASH_CAP, MVS_ROW_CAP; 4096 / 1152 in Optim::check of the 64-view build; 2048 / 448 in
+ * Filter::filterNeighbor, MVS_FILTER_ROW_CAP),
  * else 16384 (Filter::filterNeighbor's second launch). */
 void engine_neighbor_order(std::vector<int> visited, std::vector<int>& nb /* sorted unique in, slot order out */, size_t first_cap, size_t first_rows) {
     std::sort(visited.begin(), visited.end());
@@ -1234,7 +1235,7 @@ void find_neighbors(const Scene& s, const Patch& p, std::vector<int>& nb, float 
     nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
     if (s.cfg.sum_mode == ORC_SUM_TREE64) {
         const bool wide = in_check && s.list_cap > 32;  /* the 64-view engine build gives Optim::check a 4096-slot set */
-        engine_neighbor_order(visited, nb, wide ? 4096 : 2048, wide ? 1152 : 576);
+        engine_neighbor_order(visited, nb, wide ? 4096 : 2048, wide ? 1152 : (in_check ? 576 : 448));  /* Filter::filterNeighbor: MVS_FILTER_ROW_CAP */
     }
 }
 
