@@ -50,7 +50,8 @@ typedef struct mvs_patch {
     float tmp;        /* Patch::m_tmp */
     int32_t nimages;  /* m_images.size() */
     int32_t nvimages; /* m_vimages.size() */
-    int32_t flags;    /* bit 0: alive.  In exported "new" records bits 8.. hold the swept view */
+    int32_t flags;    /* bit 0: alive; bit 1: the engine's own (the list is settled: Filter::filterExact need not recompute the reference
+                       * view while the patch keeps its views; cleared on upload).  In exported "new" records bits 8.. hold the swept view */
     int32_t id;       /* pool index (download) / destination cell (exported "new" records) */
     uint8_t images[MVS_MAX_IMAGES];  /* Patch::m_images, [0] is the reference view */
     uint8_t vimages[MVS_MAX_IMAGES]; /* Patch::m_vimages */

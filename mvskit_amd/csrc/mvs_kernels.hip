@@ -812,9 +812,14 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
     for (int g = 0; g < MVS_FE_PATCHES; ++g) {
         if (!((alive_b >> ((MVS_FE_LANES * g) & 63)) & 1ull)) continue;
         DPatch* p = prm.pool + (first + (int64_t)blockIdx.x * MVS_FE_PATCHES + g);
+        const int pflags = p->flags;
         Cand c;
         load_cand(p, wc, c);
         const vmask_t sm = (vmask_t)((safe_b >> ((MVS_FE_LANES * g) & 63)) & (MVS_FE_LANES == 64 ? ~0ull : (1ull << (MVS_FE_LANES & 63)) - 1ull));  // bit i: view m_images[i] of patch g survives
+        // A patch whose list IS the outcome of this stage's setRefImage for its set of views (MVS_FLAG_SETTLED, set below) and which
+        // keeps every view: the outcome is a function of the position, the normal, the set of views and the pyramids alone (the
+        // survivors are taken in ascending view order, the axes from the first of them), so it would come out as it stands.
+        if ((pflags & MVS_FLAG_SETTLED) && (int)vpop(sm) == c.nimg) continue;
         // the survivors in ascending view order (the image-major loop of filterExactSub)
         __syncthreads();
         if (wc.lane < MVS_MAXVIEWS) s_scratch[wc.lane] = 0;
@@ -832,6 +837,7 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
         if (prm.minImageNum <= c.nimg) {
             set_ref_image(prm, wc, s_texs, tstride, c);
             store_lists(p, wc, c);
+            if (wc.lane == 0) p->flags = pflags | MVS_FLAG_SETTLED;
         } else {
             if (wc.lane == 0) kill[first + (int64_t)blockIdx.x * MVS_FE_PATCHES + g] = 1;
         }

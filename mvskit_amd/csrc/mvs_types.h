@@ -17,6 +17,8 @@
 #define MVS_NEWBASE 0x40000000  // ids >= NEWBASE: staged record NEWBASE + slot
 
 // Patch record (pmmvps/patch.hpp:33-66); same bytes as mvs_patch in include/mvskit_engine.h.
+#define MVS_FLAG_ALIVE 1
+#define MVS_FLAG_SETTLED 2  // m_images is what Filter::filterExact's setRefImage made of its current set of views (k_filter_exact)
 struct DPatch {
     float coord[4];
     float normal[4];

@@ -423,6 +423,17 @@ def test_filter_run_matches_oracle(small_multi_scene):
         np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
         o.update_threshold()
         e.update_threshold()
+    # Filter::run once more on the filtered pool: the engine does not recompute setRefImage for a patch whose list already is the
+    # outcome of filterExact for its set of views and which keeps them all (DPatch flag bit 1); the oracle recomputes every patch
+    # as the reference does (filter.cpp:148-209) -- lists and reference views must still agree
+    evals_before = e.filter_stats()["exact_view_evals"]
+    fo, fe = o.filter(), e.filter()
+    assert fo == fe, (fo, fe)
+    st = e.filter_stats()
+    assert st["exact_view_evals"] < evals_before // 10, (st, evals_before)
+    po, pe = o.patches(), e.patches()
+    np.testing.assert_array_equal(po["images"], pe["images"])
+    np.testing.assert_array_equal(po["vimages"], pe["vimages"])
 
 
 def test_filter_small_groups_literal_labelling():
