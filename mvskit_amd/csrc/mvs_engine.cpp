@@ -149,6 +149,8 @@ struct mvs_engine {
     DevBuf<int32_t> cnt_alive, vcnt_alive;
     DevBuf<unsigned long long> dpgrid, best;
     bool index_valid = false;
+    DevBuf<uint32_t> dirty;      // Filter::run: one bit per depth-map cell whose nearest patch the last stage removed
+    bool dirty_marked = false;
     bool lists_dense[2] = {false, false};  // m_pgrids / m_vpgrids index built without the trim: the lists of neighbouring cells lie end to end
     // sweep / staging
     DevBuf<DPatch> staging;
@@ -339,7 +341,7 @@ int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
 int build_depth(mvs_engine* e) {  // m_dpgrids from the alive pool
     const DParams p = current_params(e);
     HIPCHK(hipMemsetAsync(e->dpgrid.p, 0xff, (size_t)e->total_cells * sizeof(unsigned long long), e->stream));
-    mvsk_depth_maps(p, e->dpgrid.p, e->stream);
+    mvsk_depth_maps(p, e->dpgrid.p, nullptr, e->stream);
     return MVS_OK;
 }
 // Index build of a propagation pass: seed scores, m_pgrids lists with the MAX_NUM_OF_PATCHES trim, m_vpgrids lists
@@ -458,22 +460,36 @@ int literal_small_groups(mvs_engine* e, int threshold) {
     mvsk_groups_kill(p, e->uf_parent.p, e->uf_size.p, threshold, e->kill.p, st);
     return MVS_OK;
 }
-int filter_rebuild(mvs_engine* e, int additive, bool need_pgrid, bool need_vpgrid) {
+// `incr` (after a stage's removals, marked by apply_kills): 1 = the depth maps are brought up to date in the marked cells only,
+// 2 = and so is m_vimages -- allowed when the stage removed patches and left the lists of the others alone.
+int filter_rebuild(mvs_engine* e, int additive, bool need_pgrid, bool need_vpgrid, int incr = 0) {
     if (need_pgrid) { if (int r = build_list(e, false, false, true)) return r; }
-    if (int r = build_depth(e)) return r;
+    if (incr && e->dirty_marked) mvsk_depth_maps(current_params(e), e->dpgrid.p, e->dirty.p, e->stream);
+    else { incr = 0; if (int r = build_depth(e)) return r; }
+    e->dirty_marked = false;
     int64_t first, last;
     filter_range(e, first, last);
-    mvsk_filter_vimages(current_params(e), additive, first, last, e->stream);
+    mvsk_filter_vimages(current_params(e), additive, first, last, incr == 2 && additive ? e->dirty.p : nullptr, e->stream);
     if (int r = filter_exchange(e, false, true)) return r;  // m_vimages of the other ranks' patches
     if (need_vpgrid) { if (int r = build_list(e, true, false, true)) return r; }
     HIPCHK(hipGetLastError());
     return MVS_OK;
 }
 // counts and applies the kill flags a filter stage has set
-int apply_kills(mvs_engine* e, int64_t* removed) {
+// `mark` (inside Filter::run, the depth maps being those of the pool as it stands): the cells that name a patch about to be
+// removed are emptied and marked, for filter_rebuild's incremental passes
+int apply_kills(mvs_engine* e, int64_t* removed, bool mark = false) {
     hipStream_t st = e->stream;
     *removed = 0;
+    e->dirty_marked = false;
     if (e->pool_n == 0) return MVS_OK;
+    if (mark) {
+        const int64_t words = (e->total_cells + 31) / 32;
+        if (int r = e->dirty.ensure(words + 1)) return r;
+        HIPCHK(hipMemsetAsync(e->dirty.p, 0, (size_t)words * sizeof(uint32_t), st));
+        mvsk_depth_mark_dirty(current_params(e), e->kill.p, e->dpgrid.p, e->dirty.p, st);
+        e->dirty_marked = true;
+    }
     mvsk_kill_count(e->kill.p, e->pool_n, e->kill_cnt.p, st);
     mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, e->scan_tmp.p, st);
     int32_t nk = 0;
@@ -595,7 +611,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     free_views(e);
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
-    e->uf_parent.release(); e->uf_size.release(); e->group_edges.release();
+    e->uf_parent.release(); e->uf_size.release(); e->group_edges.release(); e->dirty.release();
     e->vcursor.release(); e->vids.release(); e->fat.release(); e->vfat.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
@@ -1204,9 +1220,9 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     mvsk_filter_outside(current_params(e), e->kill.p, first, last, st);          // filterOutside
     HIPCHK(hipEventRecord(e->fev[1], st));
     if (int r = filter_exchange(e, true, false)) return r;
-    if (int r = apply_kills(e, &rem[0])) return r;
+    if (int r = apply_kills(e, &rem[0], true)) return r;
     // a stage that removed nothing leaves the depth maps, hence m_vimages (additive pass) and both grids, as they are
-    if (rem[0] > 0) { if (int r = filter_rebuild(e, 1, false, false)) return r; }
+    if (rem[0] > 0) { if (int r = filter_rebuild(e, 1, false, false, 2)) return r; }
     e->fstats.exact_patches = e->fstats.patches_in - rem[0];
     HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
     HIPCHK(hipEventRecord(e->fev[2], st));
@@ -1235,8 +1251,8 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         e->fstats.exact_view_evals = (int64_t)ev2[1];
     }
     if (int r = filter_exchange(e, true, true)) return r;  // kill bytes + the rewritten m_images
-    if (int r = apply_kills(e, &rem[1])) return r;
-    if (int r = filter_rebuild(e, 1, true, true)) return r;
+    if (int r = apply_kills(e, &rem[1], true)) return r;
+    if (int r = filter_rebuild(e, 1, true, true, 1)) return r;  // filterExact rewrote m_images: every patch's m_vimages is tested anew
     e->fstats.neighbor_patches = e->fstats.exact_patches - rem[1];
     {                                                                              // filterNeighbor(1)
         if (e->uf_parent.ensure(e->pool.cap)) return MVS_ERR_HIP;                  // reused as the retry list
@@ -1256,8 +1272,8 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         HIPCHK(hipEventRecord(e->fev[5], st));
     }
     if (int r = filter_exchange(e, true, false)) return r;
-    if (int r = apply_kills(e, &rem[2])) return r;
-    if (rem[2] > 0) { if (int r = filter_rebuild(e, 1, true, true)) return r; }
+    if (int r = apply_kills(e, &rem[2], true)) return r;
+    if (rem[2] > 0) { if (int r = filter_rebuild(e, 1, true, true, 2)) return r; }
     {                                                                              // filterSmallGroups
         int64_t alive = 0;
         if (int r = mvs_engine_num_patches(e, &alive)) return r;
@@ -1267,9 +1283,9 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         if (!e->cfg.literal_groups) mvsk_groups(current_params(e), e->uf_parent.p, e->uf_size.p, threshold, e->kill.p, st);
         else if (int r = literal_small_groups(e, threshold)) return r;
         HIPCHK(hipEventRecord(e->fev[7], st));
-        if (int r = apply_kills(e, &rem[3])) return r;
+        if (int r = apply_kills(e, &rem[3], true)) return r;
     }
-    if (rem[3] > 0) { if (int r = filter_rebuild(e, 1, false, false)) return r; }
+    if (rem[3] > 0) { if (int r = filter_rebuild(e, 1, false, false, 2)) return r; }
     if (int r = compact_pool(e)) return r;
     int32_t herr = 0;
     HIPCHK(hipMemcpyAsync(&herr, e->error_flag.p, sizeof herr, hipMemcpyDeviceToHost, st));
@@ -1335,7 +1351,7 @@ int mvs_engine_depth_normal_map(mvs_engine* e, int view, int kind, float* depth,
     const unsigned long long* sel = nullptr;
     if (kind == 0) {
         HIPCHK(hipMemsetAsync(e->dpgrid.p, 0xff, (size_t)e->total_cells * sizeof(unsigned long long), st));
-        mvsk_depth_maps(p, e->dpgrid.p, st);
+        mvsk_depth_maps(p, e->dpgrid.p, nullptr, st);
         sel = e->dpgrid.p + vw.cell_base;
         e->index_valid = false;
     } else {

@@ -14,7 +14,8 @@ void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, 
 void mvsk_index_fill_direct(const DParams& prm, int vgrid, const int32_t* start, int32_t* cursor, CellEntry* fat, int32_t* id32, hipStream_t st);
 void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st);
 void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* id32, int32_t* cnt_alive, hipStream_t st);
-void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, hipStream_t st);
+void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, const uint32_t* dirty, hipStream_t st);
+void mvsk_depth_mark_dirty(const DParams& prm, const uint8_t* kill, unsigned long long* dp, uint32_t* dirty, hipStream_t st);
 void mvsk_best_ncc_map(const DParams& prm, int view, unsigned long long* best, hipStream_t st);
 void mvsk_map_extract(const DParams& prm, int view, int kind, const unsigned long long* sel, float* depth, float* normal, int32_t* ids, int ncells, hipStream_t st);
 void mvsk_fill_ncc(const DParams& prm, unsigned long long* evals, hipStream_t st);
@@ -32,7 +33,7 @@ void mvsk_apply_kill_ids(DPatch* pool, const int32_t* ids, int64_t n, int64_t po
 void mvsk_append_records(DPatch* pool, int64_t pool_n, const DPatch* recs, int64_t n, hipStream_t st);
 void mvsk_alive_count(const DPatch* pool, int64_t n, int32_t* cnt, hipStream_t st);
 void mvsk_alive_gather(const DPatch* pool, int64_t n, const int32_t* base, DPatch* out, int64_t cap, hipStream_t st);
-void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_t last, hipStream_t st);
+void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_t last, const uint32_t* dirty, hipStream_t st);
 void mvsk_filter_outside(const DParams& prm, uint8_t* kill, int64_t first, int64_t last, hipStream_t st);
 void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, int64_t first, int64_t last, hipStream_t st);
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, int64_t first, int64_t last, hipStream_t st);

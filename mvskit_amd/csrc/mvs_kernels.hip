@@ -245,7 +245,9 @@ __global__ void k_index_finalize(DParams prm, const int32_t* __restrict__ start,
 // A lane per patch, a wave per view (the four waves of a block share 64 consecutive patches and take the views in turn): patches that
 // follow each other in the pool lie next to each other on the surface, so the 64 cells a wave touches in one view's map share
 // cache lines -- with a lane per (patch, view) pair every lane of a wave wrote into another view's map.
-__global__ __launch_bounds__(256) void k_depth_maps(DParams prm, unsigned long long* __restrict__ dp) {
+// `dirty` (one bit per cell, or null): only the cells whose nearest patch a filter stage has just removed are recomputed
+// (k_depth_mark_dirty emptied them); every other cell's nearest patch is still alive, so its entry stands.
+__global__ __launch_bounds__(256) void k_depth_maps(DParams prm, unsigned long long* __restrict__ dp, const uint32_t* __restrict__ dirty) {
     const int64_t id = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63u);
     if (id >= prm.pool_n) return;
     const DPatch* p = prm.pool + id;
@@ -263,8 +265,34 @@ __global__ __launch_bounds__(256) void k_depth_maps(DParams prm, unsigned long l
             if (i == 1 && xs[1] == xs[0]) continue;  // same cell twice: idempotent, skip
             if (j == 1 && ys[1] == ys[0]) continue;
             // the cell's value only ever decreases: a plain read that already shows a nearer patch saves the atomic (most do)
-            unsigned long long* cellp = &dp[vw->cell_base + ys[j] * vw->gw + xs[i]];
+            const int cell = vw->cell_base + ys[j] * vw->gw + xs[i];
+            if (dirty && !((dirty[cell >> 5] >> (cell & 31)) & 1u)) continue;
+            unsigned long long* cellp = &dp[cell];
             if (key < __builtin_nontemporal_load(cellp)) atomicMin(cellp, key);
+        }
+    }
+}
+// Before a filter stage's removals are applied: the cells of the depth maps that name a patch about to go are emptied and marked.
+// (A cell names one patch, so only that patch's thread writes it.)
+__global__ __launch_bounds__(256) void k_depth_mark_dirty(DParams prm, const uint8_t* __restrict__ kill, unsigned long long* __restrict__ dp, uint32_t* __restrict__ dirty) {
+    const int64_t id = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63u);
+    if (id >= prm.pool_n || !kill[id]) return;
+    const DPatch* p = prm.pool + id;
+    if (!(p->flags & 1)) return;
+    const F4 coord = ld4(p->coord);
+    for (int image = (int)(threadIdx.x >> 6); image < prm.nviews; image += 4) {
+        const DView* vw = prm.views + image;
+        const F3 ic = project(vw, coord, prm.level);
+        const float fx = ic.x / (float)prm.csize, fy = ic.y / (float)prm.csize;
+        const int xs[2] = {(int)floorf(fx), (int)ceilf(fx)}, ys[2] = {(int)floorf(fy), (int)ceilf(fy)};
+        for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) {
+            if (xs[i] < 0 || vw->gw <= xs[i] || ys[j] < 0 || vw->gh <= ys[j]) continue;
+            if (i == 1 && xs[1] == xs[0]) continue;
+            if (j == 1 && ys[1] == ys[0]) continue;
+            const int cell = vw->cell_base + ys[j] * vw->gw + xs[i];
+            if ((uint32_t)(dp[cell] & 0xffffffffull) != (uint32_t)id) continue;
+            dp[cell] = ~0ull;
+            atomicOr(&dirty[cell >> 5], 1u << (cell & 31));
         }
     }
 }
@@ -690,7 +718,7 @@ DEV void store_lists(DPatch* p, const WaveCtx& wc, const Cand& c) {
 // GL lanes per patch (a lane per view; GL >= the views and >= the list storage), 64 / GL patches per wave: with 12 views a wave per
 // patch leaves 52 lanes idle through the two dependent gathers of isVisible.
 template <int GL>
-__global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive, int64_t first, int64_t last) {
+__global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive, int64_t first, int64_t last, const uint32_t* __restrict__ dirty) {
     __shared__ int s_new[64];
     const int lane = (int)threadIdx.x, g = lane / GL, i = lane % GL;
     const int64_t id = first + (int64_t)blockIdx.x * (64 / GL) + g;
@@ -712,8 +740,13 @@ __global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive
         Cand c;
         c.coord = ld4(p->coord); c.normal = ld4(p->normal);
         int ix, iy;
-        cell_of(prm, prm.views + i, c.coord, ix, iy);
-        q = is_visible(prm, c, i, ix, iy, prm.neighborThreshold) != 0;
+        const DView* vw = prm.views + i;
+        cell_of(prm, vw, c.coord, ix, iy);
+        // additive pass after removals only (`dirty`): the view was tested and found hidden when the lists were last brought up to
+        // date, and the answer can only change where the depth map did -- in a cell whose nearest patch has been removed
+        bool test = true;
+        if (dirty && !(ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy)) { const int cell = vw->cell_base + iy * vw->gw + ix; test = (dirty[cell >> 5] >> (cell & 31)) & 1u; }
+        q = test && is_visible(prm, c, i, ix, iy, prm.neighborThreshold) != 0;
     }
     const unsigned long long all = __ballot(q);
     const unsigned long long gm = GL == 64 ? all : (all >> (GL * g)) & ((1ull << (GL & 63)) - 1ull);
@@ -1082,8 +1115,11 @@ void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, unsigned lon
 void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* id32, int32_t* cnt_alive, hipStream_t st) {
     hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, fat, id32, cnt_alive);
 }
-void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_depth_maps, dim3(nblk(prm.pool_n, 64)), dim3(256), 0, st, prm, dp);
+void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, const uint32_t* dirty, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_depth_maps, dim3(nblk(prm.pool_n, 64)), dim3(256), 0, st, prm, dp, dirty);
+}
+void mvsk_depth_mark_dirty(const DParams& prm, const uint8_t* kill, unsigned long long* dp, uint32_t* dirty, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_depth_mark_dirty, dim3(nblk(prm.pool_n, 64)), dim3(256), 0, st, prm, kill, dp, dirty);
 }
 void mvsk_best_ncc_map(const DParams& prm, int view, unsigned long long* best, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_best_ncc_map, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, view, best);
@@ -1151,13 +1187,13 @@ void mvsk_alive_count(const DPatch* pool, int64_t n, int32_t* cnt, hipStream_t s
 void mvsk_alive_gather(const DPatch* pool, int64_t n, const int32_t* base, DPatch* out, int64_t cap, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_alive_gather, dim3(nblk(n, 256)), dim3(256), 0, st, pool, n, base, out, cap);
 }
-void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_t last, hipStream_t st) {
+void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_t last, const uint32_t* dirty, hipStream_t st) {
     if (last <= first) return;
     const int gl = std::max(prm.nviews <= 16 ? 16 : (prm.nviews <= 32 ? 32 : 64), (int)MVS_MAXI);
     const unsigned nb = (unsigned)((last - first + 64 / gl - 1) / (64 / gl));
-    if (gl == 16) hipLaunchKernelGGL(k_filter_vimages<16>, dim3(nb), dim3(64), 0, st, prm, additive, first, last);
-    else if (gl == 32) hipLaunchKernelGGL(k_filter_vimages<32>, dim3(nb), dim3(64), 0, st, prm, additive, first, last);
-    else hipLaunchKernelGGL(k_filter_vimages<64>, dim3(nb), dim3(64), 0, st, prm, additive, first, last);
+    if (gl == 16) hipLaunchKernelGGL(k_filter_vimages<16>, dim3(nb), dim3(64), 0, st, prm, additive, first, last, dirty);
+    else if (gl == 32) hipLaunchKernelGGL(k_filter_vimages<32>, dim3(nb), dim3(64), 0, st, prm, additive, first, last, dirty);
+    else hipLaunchKernelGGL(k_filter_vimages<64>, dim3(nb), dim3(64), 0, st, prm, additive, first, last, dirty);
 }
 void mvsk_filter_outside(const DParams& prm, uint8_t* kill, int64_t first, int64_t last, hipStream_t st) {
     if (last > first) hipLaunchKernelGGL(k_filter_outside, dim3((unsigned)(last - first)), dim3(64), 0, st, prm, kill, first);
