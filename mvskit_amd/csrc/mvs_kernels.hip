@@ -715,7 +715,7 @@ DEV void store_lists(DPatch* p, const WaveCtx& wc, const Cand& c) {
 }
 // Filter::setVGridsVPGrids (filter.cpp:657-664): m_vimages cleared (additive == 0) or kept, then setVImagesVGrids
 // (all Filter::run kernels take a patch range [first, last): a rank of a multi-GPU job filters its share of the pool)
-// GL lanes per patch (a lane per view; GL >= the views and >= the list storage), 64 / GL patches per wave: with 12 views a wave per
+// GL lanes per patch (a lane per view; GL >= the views and >= the list cap), 64 / GL patches per wave: with 12 views a wave per
 // patch leaves 52 lanes idle through the two dependent gathers of isVisible.
 template <int GL>
 __global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive, int64_t first, int64_t last, const uint32_t* __restrict__ dirty) {
@@ -760,6 +760,7 @@ __global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive
             p->images[i] = (uint8_t)(i < nimg ? my_img : 0);
             p->vimages[i] = (uint8_t)(i < nv0 ? my_vimg : (i < nv ? s_new[GL * g + (i - nv0)] : 0));
         }
+        for (int k = i + GL; k < MVS_MAXI; k += GL) { p->images[k] = 0; p->vimages[k] = 0; }  // storage beyond the list cap (GL >= MVS_LISTCAP)
     }
 }
 // Filter::filterOutside, filter.cpp:51-106: gain < 0 -> removed
@@ -1189,7 +1190,7 @@ void mvsk_alive_gather(const DPatch* pool, int64_t n, const int32_t* base, DPatc
 }
 void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_t last, const uint32_t* dirty, hipStream_t st) {
     if (last <= first) return;
-    const int gl = std::max(prm.nviews <= 16 ? 16 : (prm.nviews <= 32 ? 32 : 64), (int)MVS_MAXI);
+    const int gl = std::max(prm.nviews <= 16 ? 16 : (prm.nviews <= 32 ? 32 : 64), (int)MVS_LISTCAP);
     const unsigned nb = (unsigned)((last - first + 64 / gl - 1) / (64 / gl));
     if (gl == 16) hipLaunchKernelGGL(k_filter_vimages<16>, dim3(nb), dim3(64), 0, st, prm, additive, first, last, dirty);
     else if (gl == 32) hipLaunchKernelGGL(k_filter_vimages<32>, dim3(nb), dim3(64), 0, st, prm, additive, first, last, dirty);
