@@ -946,7 +946,7 @@ __global__ void k_groups_init(int* parent, int* size, int64_t n) {
 // symmetric.  MODE 2 (second pass): the edges that still run between two different sets, as (root of p, root of q) pairs.
 // One wave per patch: the 18 lists (3x3 cells, m_pgrids and m_vpgrids) are laid end to end and the lanes take consecutive entries, so
 // a wave reads its 48-byte entries as contiguous runs (a lane per patch reads one cache line per lane and load, and 2048 lanes per
-// CU evict each other's lines between the three loads of an entry: 24 ms per call at 1080p against 3 for this form).
+// CU evict each other's lines between the three loads of an entry: 23.7 ms per call at 1080p against 13.5 for this form).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, int2* edges, int* nedges, int cap) {
     const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
