@@ -436,6 +436,33 @@ def test_filter_run_matches_oracle(small_multi_scene):
     np.testing.assert_array_equal(po["vimages"], pe["vimages"])
 
 
+@pytest.mark.parametrize("npatch", [0, 1, 3, 5, 63, 65, 130])
+def test_filter_run_tiny_and_ragged_pools(small_plane_scene, npatch):
+    """Filter::run on pools that do not fill a wave or a block of the per-patch kernels (four patches per wave in filterExact and
+    setVImagesVGrids, 64 per block in the depth maps, four per block in filterSmallGroups' edge pass), down to the empty pool, and
+    on pools a stage empties (a handful of patches has fewer than six neighbours each: filterNeighbor removes them all and
+    filterSmallGroups meets nothing): the four removal counts and the survivors equal the oracle's."""
+    sc = small_plane_scene
+    seeds = synth.make_seeds(sc, stride=3, seed=41)[:npatch]
+    o, e = _pair(sc, seed=2, enable_check=1, minImageNum=2)
+    if npatch:
+        o.add_patches(seeds)
+        e.upload_patches(seeds)
+    for x in (o, e):
+        x.update_threshold()  # m_depth 2: isVisible tests depths
+    for _ in range(2):
+        fo, fe = o.filter(), e.filter()
+        assert fo == fe, (npatch, fo, fe)
+        po, pe = o.patches(), e.patches()
+        assert po.shape == pe.shape
+        if po.shape[0]:
+            np.testing.assert_array_equal(po["images"], pe["images"])
+            np.testing.assert_array_equal(po["vimages"], pe["vimages"])
+            np.testing.assert_array_equal(po["coord"], pe["coord"])
+    o.close()
+    e.close()
+
+
 def test_filter_small_groups_literal_labelling():
     """mvs_config.literal_groups: Filter::filterSmallGroups with the reference's own breadth-first labelling in patch order over the
     directed relation (filter.cpp:432-524) instead of the connected components.  The GPU finds the sets joined by two-way edges and the
