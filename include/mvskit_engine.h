@@ -63,7 +63,7 @@ typedef struct mvs_config {
     int32_t level;           /* Option::m_level */
     int32_t csize;           /* Option::m_csize */
     int32_t wsize;           /* Option::m_wsize (<= 7: the window's samples are dealt over the lanes of one wavefront) */
-    int32_t minImageNum;     /* Option::m_minImageNum */
+    int32_t minImageNum;     /* Option::m_minImageNum; tau = min(2 * minImageNum, nviews) must not exceed 16 */
     int32_t max_propag;      /* Propagate::MAX_NUM_OF_PROPAG, propagate.cpp:24 */
     float nccThreshold;      /* Option::m_nccThreshold */
     float maxAngleThreshold; /* Option::m_maxAngleThreshold, radians */

@@ -583,8 +583,9 @@ int mvs_engine_create(const mvs_config* cfg, mvs_engine** out) {
     if (cfg->shard_count > 1 && (cfg->shard_index < 0 || cfg->shard_index >= cfg->shard_count)) { g_err = "mvs_engine_create: bad shard_index"; return MVS_ERR_ARG; }
     if (cfg->nviews < 1 || cfg->nviews > MVS_MAXVIEWS || cfg->wsize < 1 || cfg->wsize > 7 || cfg->csize < 1 || cfg->level < 0 ||
         cfg->level > 4 || cfg->max_propag < 1 || cfg->max_propag > 16 || cfg->max_propag * cfg->csize * cfg->csize > MVS_CAPMAX ||
-        cfg->view_stride < 1 || cfg->view_begin < 0 || cfg->minImageNum < 1 || cfg->minImageNum > 8 /* tau = 2 minImageNum views sit in 16 frame lanes */) {
-        g_err = "mvs_engine_create: configuration out of range (nviews <= 64, wsize <= 7, minImageNum <= 8, max_propag*csize^2 <= 32)";
+        cfg->view_stride < 1 || cfg->view_begin < 0 || cfg->minImageNum < 1 ||
+        std::min(cfg->minImageNum * 2, cfg->nviews) > 16 /* tau (pmmvps.cpp:32) views of a proposal sit in 16 frame lanes */) {
+        g_err = "mvs_engine_create: configuration out of range (nviews <= 64, wsize <= 7, min(2 minImageNum, nviews) <= 16, max_propag*csize^2 <= 32)";
         return MVS_ERR_ARG;
     }
     int ndev = 0;

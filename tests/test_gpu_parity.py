@@ -436,6 +436,34 @@ def test_filter_run_matches_oracle(small_multi_scene):
     np.testing.assert_array_equal(po["vimages"], pe["vimages"])
 
 
+def test_min_image_num_above_eight():
+    """Option::m_minImageNum 9 on a 12-view set: tau = min(2 minImageNum, nviews) = 12 views of a proposal still sit in the 16
+    frame lanes (pmmvps.cpp:32; the engine's limit is on tau, not on minImageNum).  Two iterations with Optim::check and
+    Filter::run on a narrow arc, where every view sees the surface: counters, lists and survivors equal the oracle's."""
+    sc = synth.make_scene(nviews=12, W=160, H=120, arc_deg=22.0, radius=4.0, kind="multi")
+    seeds = synth.make_seeds(sc, stride=4, seed=11)
+    o, e = _pair(sc, seed=13, enable_check=1, minImageNum=9)
+    o.add_patches(seeds)
+    e.upload_patches(seeds)
+    for it in range(2):
+        co, ce = o.propagate(it), e.propagate(it)
+        assert co == ce, (it, co, ce)
+        fo, fe = o.filter(), e.filter()
+        assert fo == fe, (it, fo, fe)
+        o.update_threshold()
+        e.update_threshold()
+    po, pe = o.patches(), e.patches()
+    assert po.shape == pe.shape and pe.shape[0] > seeds.shape[0] // 4
+    assert int(pe["nimages"].min()) >= 9
+    np.testing.assert_array_equal(po["images"], pe["images"])
+    np.testing.assert_array_equal(po["vimages"], pe["vimages"])
+    np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+    with pytest.raises(engine.EngineError):
+        engine.Engine(20, minImageNum=9)  # tau = 18 on a 20-view set: more than the frame lanes hold
+    o.close()
+    e.close()
+
+
 @pytest.mark.parametrize("npatch", [0, 1, 3, 5, 63, 65, 130])
 def test_filter_run_tiny_and_ragged_pools(small_plane_scene, npatch):
     """Filter::run on pools that do not fill a wave or a block of the per-patch kernels (four patches per wave in filterExact and
