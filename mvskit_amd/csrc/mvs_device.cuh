@@ -1298,7 +1298,9 @@ DEV int pair_index(int a, int b, int n) { return a * (2 * n - a - 1) / 2 + (b - 
 // kt != nullptr (postProcess): the centred textures of these views are in LDS already -- the constraintImages just before
 // sampled them at this very patch with this very reference view (engine schedule: they are not sampled a second time, the
 // work counters do not count a second evaluation); entry i of the list is entry kt->orig of that evaluation.
-DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride, Cand& c, const KeptTex* kt = nullptr) {
+// `pre` (Filter::filterExact, which has the frames of four patches made side by side): lane i < nimg holds the finished frame of view c.img
+// -- made by make_frame from getPAxes of the FIRST view of the list, as below.
+DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride, Cand& c, const KeptTex* kt = nullptr, const Frame* pre = nullptr) {
     if (c.nimg == 0) return;
     const int n = c.nimg;
     const int ref = rli(c.img, 0);
@@ -1313,10 +1315,14 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
         okmask = vballot(wc.lane < n && ((kt->okm >> orig) & 1u));
         __syncthreads();
     } else {
-    F4 px, py;
-    get_paxes(prm, prm.views + ref, c.coord, c.normal, px, py);
+    Frame f;
+    if (pre) f = *pre;
+    else {
+        F4 px, py;
+        get_paxes(prm, prm.views + ref, c.coord, c.normal, px, py);
+        f = make_frame(prm, c.coord, px, py, c.normal, c.img, wc.lane < n);
+    }
     wc.evals++;
-    const Frame f = make_frame(prm, c.coord, px, py, c.normal, c.img, wc.lane < n);
     WC_ADD(wc, 1)
     // centred textures to LDS behind the frames this evaluation publishes, their ssd to view lanes
     texs += MVS_FRAME1_LDS_BYTES / 4;

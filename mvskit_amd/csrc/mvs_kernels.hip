@@ -843,6 +843,22 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
     const unsigned long long safe_b = ballot(safe);
     const unsigned long long alive_b = ballot(alive_l);
     const int tstride = prm.wsz;  // odd for 7x7 / 5x5 windows: the lane-per-pair reads of setRefImage fall in distinct banks
+    // The sampling frames of setRefImage for all patches of the wave side by side, in the lanes of the visibility phase (lane
+    // MVS_FE_LANES q + i = view i of patch q): getPAxes from the patch's first surviving view in ascending order, i.e. its smallest,
+    // and make_frame per surviving view -- once per wave, where patch by patch it ran MVS_FE_PATCHES times with a handful of lanes
+    // at work (a third of this kernel's wave time).  The loop below hands each patch's frames to its view lanes.
+    Frame fpre = {};
+    {
+        const unsigned long long gbits = MVS_FE_LANES == 64 ? ~0ull : ((1ull << (MVS_FE_LANES & 63)) - 1ull) << ((MVS_FE_LANES * q) & 63);
+        const bool skip_l = (pl->flags & MVS_FLAG_SETTLED) && (int)__popcll(safe_b & gbits) == nimg_l;  // settled and keeps every view
+        if (ballot(alive_l && !skip_l)) {
+            int vmin = safe ? image : INT_MAX;
+            for (int d = 1; d < MVS_FE_LANES; d <<= 1) vmin = min(vmin, __shfl_xor(vmin, d));
+            F4 px, py;
+            get_paxes(prm, prm.views + (vmin == INT_MAX ? 0 : vmin), coord, normal, px, py);
+            fpre = make_frame(prm, coord, px, py, normal, image, safe);
+        }
+    }
     for (int g = 0; g < MVS_FE_PATCHES; ++g) {
         if (!((alive_b >> ((MVS_FE_LANES * g) & 63)) & 1ull)) continue;
         DPatch* p = prm.pool + (first + (int64_t)blockIdx.x * MVS_FE_PATCHES + g);
@@ -858,18 +874,30 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
         __syncthreads();
         if (wc.lane < MVS_MAXVIEWS) s_scratch[wc.lane] = 0;
         __syncthreads();
-        if (wc.lane < c.nimg && ((sm >> wc.lane) & 1u)) s_scratch[c.img] = 1;
+        if (wc.lane < c.nimg && ((sm >> wc.lane) & 1u)) s_scratch[c.img] = 1 + MVS_FE_LANES * g + wc.lane;  // where this view's frame lies
         __syncthreads();
-        const bool present = s_scratch[wc.lane] != 0;
+        const int src1 = s_scratch[wc.lane];
+        const bool present = src1 != 0;
         const unsigned long long pm = ballot(present);
         const int pos = __popcll(pm & ((1ull << wc.lane) - 1ull));
         __syncthreads();
-        if (present && pos < MVS_LISTCAP) s_scratch[64 + pos] = wc.lane;
+        if (present && pos < MVS_LISTCAP) { s_scratch[64 + pos] = wc.lane; s_scratch[128 + pos] = src1 - 1; }
         __syncthreads();
         c.nimg = min((int)__popcll(pm), MVS_LISTCAP);
         c.img = s_scratch[64 + wc.lane];
         if (prm.minImageNum <= c.nimg) {
-            set_ref_image(prm, wc, s_texs, tstride, c);
+            // view lane k < nimg takes the frame of its view; the other lanes a harmless one (the origin of some view's image, ok = 0)
+            Frame f;
+            {
+                const bool mine = wc.lane < c.nimg;
+                const int src = mine ? s_scratch[128 + wc.lane] : MVS_FE_LANES * g;
+                f.tlx = __shfl(fpre.tlx, src); f.tly = __shfl(fpre.tly, src);
+                f.dxx = __shfl(fpre.dxx, src); f.dxy = __shfl(fpre.dxy, src); f.dyx = __shfl(fpre.dyx, src); f.dyy = __shfl(fpre.dyy, src);
+                f.w = __shfl(fpre.w, src); f.ok = __shfl(fpre.ok, src);
+                f.img_lo = (unsigned)__shfl((int)fpre.img_lo, src); f.img_hi = (unsigned)__shfl((int)fpre.img_hi, src);
+                if (!mine) { f.tlx = f.tly = f.dxx = f.dxy = f.dyx = f.dyy = 0.0f; f.ok = 0; }
+            }
+            set_ref_image(prm, wc, s_texs, tstride, c, nullptr, &f);  // a patch that gets here made the wave compute fpre
             store_lists(p, wc, c);
             if (wc.lane == 0) p->flags = pflags | MVS_FLAG_SETTLED;
         } else {
