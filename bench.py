@@ -237,6 +237,13 @@ def main():
     e.set_scene(sc)  # host images over PCIe + pyramids built on the device (synchronous)
     torch.cuda.synchronize()
     host_ms = {"set_views_ms": 1000.0 * (time.perf_counter() - t_h0)}
+    # the cell indexes sized once, for MAX_NUM_OF_PATCHES entries per cell, instead of growing (free + allocate, gigabytes at a
+    # time) inside the first iterations of the timed schedule -- set-up, like the pyramids; skipped where that bound is out of
+    # proportion (a 4K many-view scene: the indexes then grow as they are needed)
+    cells = args.views * ((args.width + 1) // 2) * ((args.height + 1) // 2)
+    if cells * 8 * 120 <= (16 << 30):
+        e.reserve(0)
+    torch.cuda.synchronize()
     exchange = "none"
     ex = None
     if world > 1 or args.force_exchange:

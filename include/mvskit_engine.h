@@ -141,6 +141,10 @@ int mvs_engine_update_threshold(mvs_engine* e); /* PmMvps::updateThreshold + ++m
 /* PatchManager::readPatches tail (patch_manager.cpp:450-463): seeds -> pool */
 int mvs_engine_upload_patches(mvs_engine* e, int64_t n, const mvs_patch* patches);
 int mvs_engine_clear_patches(mvs_engine* e);
+/* Optional: sizes the two cell indexes (PatchManager::m_pgrids / m_vpgrids as lists, patch_manager.hpp) for `list_entries` memberships
+ * each up front -- 0 = MAX_NUM_OF_PATCHES per cell of every view -- so that the calls below allocate nothing while the lists stay
+ * below that.  Without it the buffers grow inside the first iterations of a run. */
+int mvs_engine_reserve(mvs_engine* e, int64_t list_entries);
 int mvs_engine_num_patches(mvs_engine* e, int64_t* n_alive);
 int mvs_engine_download_patches(mvs_engine* e, int64_t cap, mvs_patch* out, int64_t* n); /* collectPatches */
 

@@ -39,6 +39,7 @@ template <typename T> struct DevBuf {
         if (n <= cap) return MVS_OK;
         // A buffer that has to grow a second time (the cell indexes of a pool that grows from iteration to iteration) takes half
         // as much again: freeing and allocating 10 GB costs ~100 ms, and an exact fit did it at every index build of a 48 x 4K run.
+        // (A caller that knows how large its pool will get sizes the indexes up front: mvs_engine_reserve.)
         int64_t want = std::max<int64_t>(n, 16);
         if (p) { (void)hipFree(p); want += want / 2; }
         p = nullptr; cap = 0;
@@ -786,6 +787,18 @@ int mvs_engine_upload_patches(mvs_engine* e, int64_t n, const mvs_patch* patches
     e->pool_n += (int64_t)recs.size();
     e->ncc_dirty = true;
     e->index_valid = false;
+    return MVS_OK;
+}
+
+// Sizes the buffers of both cell indexes for `list_entries` memberships each (0: MAX_NUM_OF_PATCHES per cell of every view, what
+// m_pgrids holds after the trim), so that Propagate::run / Filter::run allocate nothing while the lists stay below that: the first
+// iterations of a run otherwise grow them inside the call (free + allocate, gigabytes at a time).
+int mvs_engine_reserve(mvs_engine* e, int64_t list_entries) {
+    if (!e || !e->have_views || list_entries < 0) { g_err = "mvs_engine_reserve: views not set, or a negative size"; return MVS_ERR_ARG; }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    int64_t n = list_entries > 0 ? list_entries : e->total_cells * (int64_t)(e->cfg.max_propag * e->cfg.csize * e->cfg.csize);
+    n = std::min<int64_t>(n, (int64_t)INT32_MAX - 64);
+    if (e->ids.ensure(n + 16) || e->vids.ensure(n + 16) || e->fat.ensure(n + 16) || e->vfat.ensure(n + 16) || e->id32.ensure(n + 16) || e->vid32.ensure(n + 16)) return MVS_ERR_HIP;
     return MVS_OK;
 }
 

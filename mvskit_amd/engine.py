@@ -23,7 +23,7 @@ EXPORTS = [
     "mvs_engine_pass", "mvs_engine_export_counts", "mvs_engine_export_device", "mvs_engine_commit_device",
     "mvs_engine_commit_local", "mvs_engine_depth_normal_map", "mvs_engine_probe", "mvs_engine_last_timing",
     "mvs_engine_filter", "mvs_comm_unique_id", "mvs_engine_comm_init", "mvs_engine_comm_attach", "mvs_engine_comm_release",
-    "mvs_engine_exchange", "mvs_list_cap", "mvs_engine_filter_stats", "mvs_patch_bytes",
+    "mvs_engine_exchange", "mvs_list_cap", "mvs_engine_filter_stats", "mvs_patch_bytes", "mvs_engine_reserve",
 ]
 
 
@@ -122,6 +122,7 @@ def load_library(cap32: bool = False, cap: int = 0):
     L.mvs_engine_exchange.argtypes = [vp]
     L.mvs_list_cap.restype = C.c_int
     L.mvs_patch_bytes.restype = C.c_int
+    L.mvs_engine_reserve.argtypes = [vp, C.c_int64]
     L.mvs_engine_filter_stats.argtypes = [vp, C.POINTER(FilterStats)]
     _libs[LIB_PATH] = L
     return L
@@ -217,6 +218,10 @@ class Engine:
         self._check(self.L.mvs_engine_upload_patches(self.h, recs.shape[0], _ptr(recs)))
 
     add_patches = upload_patches
+
+    def reserve(self, list_entries=0):
+        """Sizes the cell indexes up front (0: MAX_NUM_OF_PATCHES per cell of every view): no allocation inside the iterations."""
+        self._check(self.L.mvs_engine_reserve(self.h, int(list_entries)))
 
     def clear_patches(self):
         self._check(self.L.mvs_engine_clear_patches(self.h))
