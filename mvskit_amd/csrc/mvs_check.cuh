@@ -440,6 +440,46 @@ DEV double wave_sum_f64_l63(double x) {
     x = x + dpp_d<0x143, 0xc>(x);
     return x;
 }
+// N sums per lane -> one lane per sum, through the same tree of additions as wave_sum_f64 (neighbouring lanes, pairs of pairs, ...,
+// rows, pairs of rows, halves): at the step over distance D the lower lane of a pair keeps the first (N + 1) / 2 of the sums and hands
+// over the rest, the upper lane the other way round, and each adds what it receives to what it keeps -- the two operands of every
+// addition are those of the butterfly (addition commutes), but N + N/2 + N/4 + ... of them are made instead of 6 N.
+template <int D> DEV double xchg_f64(double x) {
+    if (D == 1) return dpp_d<0xB1, 0xf>(x);  // quad_perm [1, 0, 3, 2]
+    if (D == 2) return dpp_d<0x4E, 0xf>(x);  // quad_perm [2, 3, 0, 1]
+    const long long b = __double_as_longlong(x);
+    const int lo = __shfl_xor((int)(b & 0xffffffffll), D), hi = __shfl_xor((int)(b >> 32), D);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+template <int N, int D> DEV void scatter_step_f64(double* v, int lane) {
+    constexpr int K = (N + 1) / 2;
+    const bool up = (lane & D) != 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const double first = v[j], second = (K + j < N) ? v[K + j] : 0.0;
+        const double keep = up ? second : first, send = up ? first : second;
+        v[j] = keep + xchg_f64<D>(send);
+    }
+}
+// v[0..20) in every lane -> the wave's sum k in v[0] of lane owner(k); returns the k this lane owns, or -1
+DEV int wave_sums20_f64(double* v, int lane) {
+    scatter_step_f64<20, 1>(v, lane);
+    scatter_step_f64<10, 2>(v, lane);
+    scatter_step_f64<5, 4>(v, lane);
+    scatter_step_f64<3, 8>(v, lane);
+    scatter_step_f64<2, 16>(v, lane);
+    scatter_step_f64<1, 32>(v, lane);
+    // which sum ended up in this lane's v[0]: every step works on the same array length N in all lanes (20, 10, 5, 3, 2, 1), of which
+    // a lane's first `cnt` entries are sums (the upper lane of a step may get fewer than the lower one), v[0] being sum `off`
+    int off = 0, cnt = 20, len = 20;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int k = (len + 1) / 2;
+        if (lane & d) { off += k; cnt = max(cnt - k, 0); } else cnt = min(cnt, k);
+        len = k;
+    }
+    return cnt >= 1 ? off : -1;
+}
 DEV double shfl_f64(double x, int src) {
     const long long b = __double_as_longlong(x);
     const int lo = __shfl((int)(b & 0xffffffffll), src), hi = __shfl((int)(b >> 32), src);
@@ -486,10 +526,9 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
     // matrix instead of 60 uniform registers.
     double* sums = sums_lds ? sums_lds : reinterpret_cast<double*>(rows + 3 * ((n + 1) & ~1));  // behind the rows, 8-byte aligned (always LDS)
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 20; ++k) {
-        const double v = wave_sum_f64_l63(acc[k]);
-        if (wc.lane == 63) sums[k] = v;
+    {
+        const int mine = wave_sums20_f64(acc, wc.lane);
+        if (mine >= 0) sums[mine] = acc[0];
     }
     __syncthreads();
     const int lr = min(wc.lane / 6, 4), lc = wc.lane % 6;
