@@ -710,6 +710,11 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
         return MVS_ERR_HIP;
     const int64_t scan_n = std::max<int64_t>(std::max<int64_t>(nc, pool_cap), njobs_max);
     if (e->scan_tmp.ensure(scan_n / 256 + 4096)) return MVS_ERR_HIP;
+    // Optim::check's second tier: its global-memory id sets and the list of cells to run again (16 MB + 4 B per job) -- here, not in the
+    // first pass with check, so that no pass allocates
+    if (e->big_tables.ensure((int64_t)256 * 16384) || e->retry_jobs.ensure(std::max<int64_t>(njobs_max, 16))) return MVS_ERR_HIP;
+    // likewise what Filter::run needs per patch and per cell (union-find, retry list, the bit per depth-map cell)
+    if (e->uf_parent.ensure(pool_cap) || e->uf_size.ensure(pool_cap) || e->dirty.ensure((nc + 31) / 32 + 1) || e->fstat_buf.ensure(4096)) return MVS_ERR_HIP;
     if (e->staging.ensure(std::max<int64_t>(pool_cap / 2, 1024))) return MVS_ERR_HIP;
     if (e->tmp_rec_out.ensure(16)) return MVS_ERR_HIP;
     HIPCHK(hipStreamSynchronize(st));
