@@ -1016,10 +1016,10 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
         const CellEntry e = (l_kind == 0 ? prm.csr_fat : prm.vcsr_fat)[l_start + (k - l_first)];
         if (e.id == (int)id) continue;
         const PGeo q{{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
-        if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) continue;
-        // two patches that hang on the same node are in one set already: one load instead of the two root searches of a union --
-        // the common case once the large component has formed and its paths are short
+        // two patches that hang on the same node are in one set already: one load instead of the predicate and the two root searches
+        // of a union -- the common case once the large component has formed and its paths are short
         if (MODE != 2 && __atomic_load_n(&parent[e.id], __ATOMIC_RELAXED) == __atomic_load_n(&parent[id], __ATOMIC_RELAXED)) continue;
+        if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) continue;
         if (MODE == 0) uf_union(parent, (int)id, e.id);
         else if (MODE == 1) {
             if (!((listed >> e.ref) & 1ull)) continue;
