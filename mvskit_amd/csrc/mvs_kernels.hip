@@ -1006,28 +1006,32 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
     const int total = __builtin_amdgcn_readlane(before, 17);
     before -= ln;
     int myroot = -1;
-    for (int k0 = 0; k0 < total; k0 += 64) {
-        const int k = k0 + lane;
-        int lo = 0;  // the list entry k falls in: the last lane whose list begins at or before k (lanes 18.. hold the total; an empty list never wins)
+    // entry k of the 18 lists laid end to end: the list it falls in is the last lane whose list begins at or before k (lanes 18.. hold the
+    // total; an empty list never wins)
+    auto entry_at = [&](int k, CellEntry& e) -> bool {
+        int lo = 0;
 #pragma unroll
         for (int step = 16; step >= 1; step >>= 1) { const int pc = __shfl(before, lo + step); if (pc <= k) lo += step; }
-        const int l_first = __shfl(before, lo), l_start = __shfl(lstart, lo), l_kind = lo >= 9 ? 1 : 0;
-        if (k >= total) continue;
-        const CellEntry e = (l_kind == 0 ? prm.csr_fat : prm.vcsr_fat)[l_start + (k - l_first)];
-        if (e.id == (int)id) continue;
-        const PGeo q{{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
+        const int l_first = __shfl(before, lo), l_start = __shfl(lstart, lo);
+        if (k >= total) return false;
+        e = (lo >= 9 ? prm.vcsr_fat : prm.csr_fat)[l_start + (k - l_first)];
+        return true;
+    };
+    auto edge = [&](const CellEntry& e) {
+        if (e.id == (int)id) return;
         // two patches that hang on the same node are in one set already: one load instead of the predicate and the two root searches
         // of a union -- the common case once the large component has formed and its paths are short
-        if (MODE != 2 && __atomic_load_n(&parent[e.id], __ATOMIC_RELAXED) == __atomic_load_n(&parent[id], __ATOMIC_RELAXED)) continue;
-        if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) continue;
+        if (MODE != 2 && __atomic_load_n(&parent[e.id], __ATOMIC_RELAXED) == __atomic_load_n(&parent[id], __ATOMIC_RELAXED)) return;
+        const PGeo q{{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
+        if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) return;
         if (MODE == 0) uf_union(parent, (int)id, e.id);
         else if (MODE == 1) {
-            if (!((listed >> e.ref) & 1ull)) continue;
+            if (!((listed >> e.ref) & 1ull)) return;
             const DView* qw = prm.views + e.ref;
             int px, py, qx, qy;
             cell_of(prm, qw, me.coord, px, py);
             cell_of(prm, qw, q.coord, qx, qy);
-            if (px < 0 || qw->gw <= px || py < 0 || qw->gh <= py) continue;
+            if (px < 0 || qw->gw <= px || py < 0 || qw->gh <= py) return;
             if (abs(px - qx) <= 1 && abs(py - qy) <= 1) uf_union(parent, (int)id, e.id);
         } else {
             if (myroot < 0) myroot = uf_find(parent, (int)id);
@@ -1037,6 +1041,12 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
                 if (k2 < cap) edges[k2] = make_int2(myroot, rq);
             }
         }
+    };
+    for (int k0 = 0; k0 < total; k0 += 128) {  // two rounds of entries in flight (a patch meets ~120)
+        CellEntry e0, e1;
+        const bool h0 = entry_at(k0 + lane, e0), h1 = entry_at(k0 + 64 + lane, e1);
+        if (h0) edge(e0);
+        if (h1) edge(e1);
     }
 }
 __global__ void k_groups_count(DParams prm, int* parent, int* size) {
