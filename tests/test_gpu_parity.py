@@ -436,6 +436,30 @@ def test_filter_run_matches_oracle(small_multi_scene):
     np.testing.assert_array_equal(po["vimages"], pe["vimages"])
 
 
+def test_reserve_sizes_the_indexes_up_front(small_multi_scene):
+    """mvs_engine_reserve: the cell indexes allocated once (default: MAX_NUM_OF_PATCHES entries per cell) -- the iterations that
+    follow compute what they compute without it (two iterations with Optim::check and Filter::run against the oracle), a smaller
+    request later changes nothing, a negative one is refused."""
+    sc = small_multi_scene
+    seeds = synth.make_seeds(sc, stride=3, seed=19)
+    o, e = _pair(sc, seed=21, enable_check=1)
+    e.reserve()
+    o.add_patches(seeds)
+    e.upload_patches(seeds)
+    for it in range(2):
+        co, ce = o.propagate(it), e.propagate(it)
+        assert co == ce, (it, co, ce)
+        e.reserve(1000)
+        fo, fe = o.filter(), e.filter()
+        assert fo == fe, (it, fo, fe)
+        o.update_threshold()
+        e.update_threshold()
+    with pytest.raises(engine.EngineError):
+        e.reserve(-1)
+    o.close()
+    e.close()
+
+
 def test_min_image_num_above_eight():
     """Option::m_minImageNum 9 on a 12-view set: tau = min(2 minImageNum, nviews) = 12 views of a proposal still sit in the 16
     frame lanes (pmmvps.cpp:32; the engine's limit is on tau, not on minImageNum).  Two iterations with Optim::check and
