@@ -29,7 +29,8 @@ extern "C" {
 #ifndef MVS_MAX_IMAGES
 #define MVS_MAX_IMAGES 32 /* storage of Patch::m_images / m_vimages in a record; 64 for libmvskit_engine_cap64.so (compile callers with -DMVS_MAX_IMAGES=64) */
 #endif
-#define MVS_LIST_CAP 16   /* lists are truncated to this many views in the default build; see mvs_list_cap() */
+#define MVS_LIST_CAP 16   /* list length of the DEFAULT build (libmvskit_engine.so); the cap32 / cap64 builds hold 32 / 64 views per list.  A library
+                           * that holds the data set's view count never cuts a list; ask the loaded one with mvs_list_cap() */
 
 typedef enum mvs_status {
     MVS_OK = 0,
@@ -115,15 +116,26 @@ typedef struct mvs_engine mvs_engine;
 
 const char* mvs_last_error(void);
 int mvs_device_count(void);
-/* Patch::m_images / m_vimages are unbounded in the reference (optim.cpp:165-205 pushes every qualifying view); the engine
- * keeps them in wavefront lanes and LDS and truncates them: to 16 views in libmvskit_engine.so, to 32 in
- * libmvskit_engine_cap32.so (the same sources built with -DMVS_LISTCAP=32: twice the setRefImage LDS, 2 waves per SIMD),
- * which is the library to load for data sets of more than 16 views. */
+/* Patch::m_images / m_vimages are unbounded in the reference (optim.cpp:165-205 pushes every qualifying view); the engine keeps
+ * them in wavefront lanes, one view per lane.  Three builds of the same sources: libmvskit_engine.so holds 16 views per list,
+ * libmvskit_engine_cap32.so 32, libmvskit_engine_cap64.so 64 (= the engine's view limit; 192-byte records).  Load the smallest one
+ * whose mvs_list_cap() >= the data set's view count: then NO list is ever cut.  A smaller library on a larger data set keeps the
+ * first mvs_list_cap() entries of a list (mvskit_amd.engine.Engine and the host mirror pick the library by view count). */
 int mvs_list_cap(void);
 int mvs_patch_bytes(void); /* sizeof(mvs_patch) in this build of the library: 128, or 192 in libmvskit_engine_cap64.so -- a caller checks it against its own */
 void mvs_default_config(mvs_config* cfg); /* Option::Option, option.cpp:19-33 */
 
-/* PmMvps::init (pmmvps.cpp:18-68): thresholds, tau = min(2*minImageNum, nviews), maxLevel = level+3 */
+/* PmMvps::init (pmmvps.cpp:18-68): thresholds, tau = min(2*minImageNum, nviews), maxLevel = level+3.
+ * LIMITS -- Option::init (pmmvps/option.cpp:53-116) takes any value; the engine returns MVS_ERR_ARG outside these:
+ *     nviews            1 .. 64      one wavefront lane per view in the per-view stages (64-view lists need libmvskit_engine_cap64.so)
+ *     wsize             1 .. 7       the wsize^2 samples of a window are dealt over 3 slots x 16 lanes + one extra sample (49)
+ *     tau               <= 16        tau = min(2 * minImageNum, nviews) views of a proposal sit in 16 frame lanes: any minImageNum
+ *                                    on <= 16 views, minImageNum <= 8 beyond
+ *     max_propag*csize^2 <= 32       MAX_NUM_OF_PATCHES (propagate.cpp:24-25): a cell's live list is held in 32 lanes; max_propag <= 16
+ *     level             0 .. 4       level + 3 pyramid levels, 7 at most
+ *     images            >= 8 x 8 pixels at level 0 (mvs_engine_set_views)
+ * and MVS_ERR_CAPACITY at run time beyond: max_patches records in the pool (default 4 per cell), 2^30 patches (ids of staged
+ * records start at 0x40000000), and 14336 distinct patches / 4064 neighbours around one patch in Optim::check / filterNeighbor. */
 int mvs_engine_create(const mvs_config* cfg, mvs_engine** out);
 int mvs_engine_destroy(mvs_engine* e);
 
@@ -189,8 +201,10 @@ int mvs_engine_commit_local(mvs_engine* e);
 /* ---- multi-GPU through the C ABI (no reference counterpart: the reference is one thread on one CPU).
  * One engine per process and GPU; every engine is created with shard_index = rank, shard_count = world, holds the whole
  * pool and all pyramids, and sweeps its contiguous range of the (view, cell) job sequence.  The engines of a job share an
- * RCCL communicator; after each colour pass mvs_engine_exchange all-gathers, on the engine's own stream, (1) the counts
- * (one ncclAllGather of two int64 per rank), (2) the new 128-byte records, each rank's block broadcast straight into its
+ * RCCL communicator; after each colour pass mvs_engine_exchange all-gathers, on the engine's own stream, (1) five int64 per
+ * rank in ONE ncclAllGather -- {new records, evicted ids, this rank's status of the pass, pool headroom, kill-id capacity}: a rank
+ * whose pass failed makes every rank give the pass up and return the same status from the same call -- (2) the new records
+ * (sizeof(mvs_patch) bytes each), each rank's block broadcast straight into its
  * final place behind the pool (ranges are contiguous, so rank order IS the global (view, cell, creation) order), and
  * (3) the ids of evicted patches -- then commits the union, so all pools stay identical and equal to the 1-GPU result.
  * With a communicator attached, mvs_engine_propagate does pass + exchange itself: PmMvps::run needs no other change.

@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(LIB_DIR, "libmvskit_engine.so")
 LIB32_PATH = os.path.join(LIB_DIR, "libmvskit_engine_cap32.so")  # the same sources with 32-view lists (-DMVS_LISTCAP=32)
 LIB64_PATH = os.path.join(LIB_DIR, "libmvskit_engine_cap64.so")  # 64-view lists and 192-byte records (-DMVS_LISTCAP=64 -DMVS_MAX_IMAGES=64)
 ENGINE_LIBS = {16: LIB_PATH, 32: LIB32_PATH, 64: LIB64_PATH}
+# TEST build of the 16-view engine with the fault-injection hooks compiled in (-DMVS_FAULT_INJECTION: MVS_FAULT_PASS / MVS_FAULT_FILTER in the
+# environment make one rank fail at a chosen point).  tests/test_gpu_dist.py loads it; the product libraries never read those variables.
+FAULT_LIB_PATH = os.path.join(LIB_DIR, "libmvskit_engine_faultinj.so")
 CAP_FLAGS = {16: [], 32: ["-DMVS_LISTCAP=32"], 64: ["-DMVS_LISTCAP=64", "-DMVS_MAX_IMAGES=64"]}
 SOURCES = ["mvs_kernels.hip", "mvs_engine.cpp"]
 DEPS = SOURCES + ["mvs_device.cuh", "mvs_check.cuh", "mvs_types.h", "mvs_kernels.h", os.path.join(ROOT, "include", "mvskit_engine.h")]
@@ -37,15 +40,16 @@ def needs_build(path: str = LIB_PATH) -> bool:
     return False
 
 
-def build_engine(force: bool = False, verbose: bool = False, cap32: bool = False, cap: int = 0) -> str:
-    """cap: 16 (default), 32 or 64 views per m_images / m_vimages list (cap32=True is cap=32)."""
+def build_engine(force: bool = False, verbose: bool = False, cap32: bool = False, cap: int = 0, fault_injection: bool = False) -> str:
+    """cap: 16 (default), 32 or 64 views per m_images / m_vimages list (cap32=True is cap=32).
+    fault_injection: the 16-view TEST build with -DMVS_FAULT_INJECTION (FAULT_LIB_PATH)."""
     cap = cap or (32 if cap32 else 16)
-    out = ENGINE_LIBS[cap]
+    out = FAULT_LIB_PATH if fault_injection else ENGINE_LIBS[cap]
     if not force and not needs_build(out):
         return out
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + CAP_FLAGS[cap] + os.environ.get("MVS_EXTRA_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + CAP_FLAGS[cap] + (["-DMVS_FAULT_INJECTION"] if fault_injection else []) + os.environ.get("MVS_EXTRA_FLAGS", "").split()
     cmd += ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out, "-ldl"]
     if verbose:
@@ -87,3 +91,4 @@ if __name__ == "__main__":
     for c in (16, 32, 64):
         print(build_engine(force=True, verbose=True, cap=c))
         print(build_host(force=True, verbose=True, cap=c))
+    print(build_engine(force=True, verbose=True, fault_injection=True))

@@ -97,21 +97,33 @@ DEV int is_neighbor_radius(const DParams& prm, const PGeo& l, const PGeo& r, flo
     return ftmp < thr ? 1 : 0;
 }
 
-// List of (kind, view, cell): kind 0 = m_pgrids, 1 = m_vpgrids.  Snapshot lists are contiguous CellEntry streams
-// (alive entries only); the destination cell being processed is read through its live id list instead.
+// List of (kind, view, cell): kind 0 = m_pgrids, 1 = m_vpgrids.  Snapshot lists are contiguous streams (alive entries only) -- fat
+// CellEntry records, or in the slim index the ids alone, the geometry then coming from the pool record; the destination cell being
+// processed is read through its live id list instead.
 struct ListRef { const CellEntry* fat; const int32_t* ids; int n; bool live; };
 DEV ListRef cell_span(const DParams& prm, const CheckCtx& cx, int kind, int view, int cell) {
     if (kind == 0 && view == cx.live_view && cell == cx.live_cell) return {nullptr, nullptr, cx.live_n, true};
     const int g = (prm.views + view)->cell_base + cell;
-    if (kind == 0) { const int b = prm.csr_start[g]; return {prm.csr_fat + b, prm.csr_id32 + b, prm.csr_cnt[g], false}; }
-    const int b = prm.vcsr_start[g];
+#if MVS_FAT_INDEX
+    if (kind == 0) { const csr_off_t b = prm.csr_start[g]; return {prm.csr_fat + b, prm.csr_id32 + b, prm.csr_cnt[g], false}; }
+    const csr_off_t b = prm.vcsr_start[g];
     return {prm.vcsr_fat + b, prm.vcsr_id32 + b, prm.vcsr_cnt[g], false};
+#else
+    if (kind == 0) { const csr_off_t b = prm.csr_start[g]; return {nullptr, prm.csr_id32 + b, prm.csr_cnt[g], false}; }
+    const csr_off_t b = prm.vcsr_start[g];
+    return {nullptr, prm.vcsr_id32 + b, prm.vcsr_cnt[g], false};
+#endif
 }
 DEV PGeo entry_geo(const DParams& prm, const CheckCtx& cx, const ListRef& l, int j, int& id) {
     if (l.live) { id = cx.live_ids[j]; return load_geo(patch_ptr(prm, cx, id)); }
+#if MVS_FAT_INDEX
     const CellEntry e = l.fat[j];
     id = e.id;
     return {{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
+#else
+    id = l.ids[j];
+    return load_geo(prm.pool + id);  // a snapshot list names pool patches only
+#endif
 }
 
 // Filter::computeGain, filter.cpp:108-146.  One lane per (view, list entry) pair -- a list holds at most
@@ -308,15 +320,16 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
             const int i = rc / (2 * side), dy = rc % side - margin;
             const bool vk = ((rc / side) & 1) != 0;
             const int v = __shfl(c.img, i), gx = __shfl(c.gx, i), gy = __shfl(c.gy, i);
-            int b = 0, len = 0;
+            csr_off_t b = 0;
+            int len = 0;
             if (r < nrow) {
                 const DView* vw = prm.views + v;
                 const int yt = gy + dy, x0 = max(gx - margin, 0), x1 = min(gx + margin, vw->gw - 1);
                 if (0 <= yt && yt < vw->gh && x0 <= x1) {
-                    const int32_t* st = vk ? prm.vcsr_start : prm.csr_start;
+                    const csr_off_t* st = vk ? prm.vcsr_start : prm.csr_start;
                     const int g0 = vw->cell_base + yt * vw->gw + x0;
                     b = st[g0];
-                    len = st[g0 + (x1 - x0) + 1] - b;
+                    len = (int)(st[g0 + (x1 - x0) + 1] - b);
                 }
             }
             int P = len;  // the running total over the lanes: inclusive, then exclusive
@@ -332,7 +345,8 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
                     int lo = 0;  // the run id k falls in: the last lane whose run begins at or before k
 #pragma unroll
                     for (int step = 32; step >= 1; step >>= 1) { const int pc = __shfl(P, lo + step); if (pc <= k) lo += step; }
-                    const int bb = __shfl(b, lo), pl = __shfl(P, lo);
+                    const csr_off_t bb = __shfl(b, lo);
+                    const int pl = __shfl(P, lo);
                     const bool kv = (((r0 + lo) / side) & 1) != 0;
                     id[u] = k < total ? (kv ? prm.vcsr_id32 : prm.csr_id32)[bb + (k - pl)] : MVS_SET_EMPTY;
                 }

@@ -35,18 +35,28 @@ thread_local std::string g_err;
 template <typename T> struct DevBuf {
     T* p = nullptr;
     int64_t cap = 0;
+    bool headroom = false;  // the cell indexes only: a buffer that has to grow a second time takes half as much again
     int ensure(int64_t n) {
         if (n <= cap) return MVS_OK;
-        // A buffer that has to grow a second time (the cell indexes of a pool that grows from iteration to iteration) takes half
-        // as much again: freeing and allocating 10 GB costs ~100 ms, and an exact fit did it at every index build of a 48 x 4K run.
-        // (A caller that knows how large its pool will get sizes the indexes up front: mvs_engine_reserve.)
-        int64_t want = std::max<int64_t>(n, 16);
-        if (p) { (void)hipFree(p); want += want / 2; }
-        p = nullptr; cap = 0;
-        hipError_t e = hipMalloc((void**)&p, (size_t)want * sizeof(T));
-        if (e != hipSuccess && want > n) { (void)hipGetLastError(); want = std::max<int64_t>(n, 16); e = hipMalloc((void**)&p, (size_t)want * sizeof(T)); }  // no room for the headroom
-        if (e != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return MVS_ERR_HIP; }
-        cap = want;
+        // (headroom) The cell indexes of a pool that grows from iteration to iteration: freeing and allocating 10 GB costs ~100 ms, and an
+        // exact fit did it at every index build of a 48 x 4K run.  (A caller that knows how large its pool will get sizes the indexes
+        // up front: mvs_engine_reserve.)  Every other buffer gets exactly what it asks for.
+        const int64_t exact = std::max<int64_t>(n, 16);
+        int64_t want = (p && headroom) ? exact + exact / 2 : exact;
+        // The contents are never needed across a growth.  The new buffer is allocated BEFORE the old one is freed where both fit, so
+        // that a failure leaves the old buffer in place (a failed mvs_engine_reserve must not take the indexes away); if they do not
+        // fit side by side the old one goes first.
+        T* q = nullptr;
+        hipError_t e = hipMalloc((void**)&q, (size_t)want * sizeof(T));
+        if (e != hipSuccess && want > exact) { (void)hipGetLastError(); want = exact; e = hipMalloc((void**)&q, (size_t)want * sizeof(T)); }  // no room for the headroom
+        if (e != hipSuccess && p) {
+            (void)hipGetLastError();
+            (void)hipFree(p); p = nullptr; cap = 0;
+            e = hipMalloc((void**)&q, (size_t)want * sizeof(T));
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return MVS_ERR_HIP; }
+        if (p) (void)hipFree(p);
+        p = q; cap = want;
         return MVS_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -144,10 +154,13 @@ struct mvs_engine {
     int64_t pool_n = 0;
     bool ncc_dirty = false;
     // index
-    DevBuf<int32_t> cnt, start, cursor, vcnt, vstart, vcursor, scan_tmp;
-    DevBuf<unsigned long long> ids, vids;  // list entries of the index build: (descending ncc, id) sort keys
-    DevBuf<CellEntry> fat, vfat;
-    DevBuf<int32_t> id32, vid32;  // the ids of fat / vfat alone
+    DevBuf<int32_t> cnt, cursor, vcnt, vcursor;
+    DevBuf<csr_off_t> start, vstart;       // list offsets: 32-bit in the fat index, 64-bit in the slim one (mvs_types.h)
+    DevBuf<int64_t> scan_tmp;              // block sums of the scans (used as int32 or as csr_off_t)
+    DevBuf<unsigned long long> ids;        // the (descending ncc, id) sort keys of an index build: transient, one buffer serves both grids
+    DevBuf<CellEntry> fat, vfat;           // MVS_FAT_INDEX: the 48-byte entries
+    DevBuf<ListKey> key;                   // slim index: (m_ncc, reference view) per m_pgrids entry
+    DevBuf<int32_t> id32, vid32;           // the ids alone
     DevBuf<int32_t> uf_parent, uf_size;  // Filter::filterSmallGroups union-find
     DevBuf<int32_t> group_edges;         // its literal labelling: (root, root) pairs of the one-way edges between sets
     DevBuf<int32_t> cnt_alive, vcnt_alive;
@@ -289,7 +302,7 @@ DParams current_params(mvs_engine* e) {
     p.pool = e->pool.p;
     p.pool_n = e->pool_n;
     p.total_cells = e->total_cells;
-    p.csr_start = e->start.p; p.csr_cnt = e->cnt_alive.p; p.csr_fat = e->fat.p; p.csr_id32 = e->id32.p;
+    p.csr_start = e->start.p; p.csr_cnt = e->cnt_alive.p; p.csr_fat = e->fat.p; p.csr_key = e->key.p; p.csr_id32 = e->id32.p;
     p.vcsr_start = e->vstart.p; p.vcsr_cnt = e->vcnt_alive.p; p.vcsr_fat = e->vfat.p; p.vcsr_id32 = e->vid32.p;
     p.dpgrid = e->dpgrid.p;
     return p;
@@ -305,27 +318,33 @@ int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
     const int64_t nc = e->total_cells;
     DParams p = current_params(e);
     DevBuf<int32_t>& cnt = vgrid ? e->vcnt : e->cnt;
-    DevBuf<int32_t>& start = vgrid ? e->vstart : e->start;
+    DevBuf<csr_off_t>& start = vgrid ? e->vstart : e->start;
     DevBuf<int32_t>& cursor = vgrid ? e->vcursor : e->cursor;
-    DevBuf<unsigned long long>& ids = vgrid ? e->vids : e->ids;
+    DevBuf<unsigned long long>& ids = e->ids;
     DevBuf<CellEntry>& fat = vgrid ? e->vfat : e->fat;
     DevBuf<int32_t>& id32 = vgrid ? e->vid32 : e->id32;
     DevBuf<int32_t>& cnt_alive = vgrid ? e->vcnt_alive : e->cnt_alive;
     HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(e->misc.p + 6, 0, sizeof(unsigned long long), st));
     mvsk_index_count(p, vgrid ? nullptr : cnt.p, vgrid ? cnt.p : nullptr, e->misc.p + 6, st);
-    mvsk_exclusive_scan(cnt.p, start.p, nc, e->scan_tmp.p, st);
-    int32_t tot = 0;
+    mvsk_exclusive_scan_off(cnt.p, start.p, nc, reinterpret_cast<csr_off_t*>(e->scan_tmp.p), st);
     unsigned long long tot64 = 0;
-    HIPCHK(hipMemcpyAsync(&tot, start.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&tot64, e->misc.p + 6, sizeof tot64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (tot64 > (unsigned long long)(INT32_MAX - 64)) {  // every patch sits in the cell list of each of its views: offsets are 32-bit
-        g_err = "cell index: more than 2^31 list entries (patches x views per patch); lower mvs_config.max_patches";
+#if MVS_FAT_INDEX
+    if (tot64 > (unsigned long long)(INT32_MAX - 64)) {  // every patch sits in the cell list of each of its views: this build's offsets are 32-bit
+        g_err = "cell index: more than 2^31 list entries (patches x views per patch) -- the build with the slim index (-DMVS_FAT_INDEX=0; "
+                "libmvskit_engine_cap64.so has it) takes them";
         return MVS_ERR_CAPACITY;
     }
+#endif
+    const int64_t tot = (int64_t)tot64;
     if (!unordered) { if (int r = ids.ensure(tot + 16)) return r; }
+#if MVS_FAT_INDEX
     if (int r = fat.ensure(tot + 16)) return r;
+#else
+    if (!vgrid && !unordered) { if (int r = e->key.ensure(tot + 16)) return r; }
+#endif
     if (int r = id32.ensure(tot + 16)) return r;
     p = current_params(e);
     HIPCHK(hipMemsetAsync(cursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
@@ -335,10 +354,9 @@ int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
         e->lists_dense[vgrid ? 1 : 0] = true;
         return MVS_OK;
     }
-    mvsk_index_fill(p, vgrid ? nullptr : start.p, vgrid ? nullptr : cursor.p, vgrid ? nullptr : ids.p, vgrid ? start.p : nullptr,
-                    vgrid ? cursor.p : nullptr, vgrid ? ids.p : nullptr, st);
+    mvsk_index_fill(p, vgrid ? 1 : 0, start.p, cursor.p, ids.p, st);
     mvsk_index_sort_trim(p, start.p, ids.p, trim ? 1 : 0, e->misc.p + 3, st);
-    mvsk_index_finalize(p, start.p, ids.p, fat.p, id32.p, cnt_alive.p, st);
+    mvsk_index_finalize(p, vgrid ? 1 : 0, start.p, ids.p, fat.p, e->key.p, id32.p, cnt_alive.p, st);
     e->lists_dense[vgrid ? 1 : 0] = !trim;
     return MVS_OK;
 }
@@ -385,8 +403,77 @@ void filter_range(const mvs_engine* e, int64_t& first, int64_t& last) {
         last = e->pool_n * (e->comm_rank + 1) / e->comm_world;
     }
 }
-int filter_exchange(mvs_engine* e, bool kills, bool records) {
-    if (!e->comm || e->comm_world <= 1 || e->pool_n == 0) return MVS_OK;
+// A failure on ONE rank inside the collective Filter::run (an allocation that does not fit there, a HIP error) must not leave the
+// others waiting in the next broadcast.  Every step of the call goes through FilterRun: after a local failure the rank does no more
+// work of its own and only keeps the appointments -- an agreement (one int64 per rank, all-gathered) stands in front of EVERY
+// collective of the call, so the next collective any rank reaches is an agreement, in which all ranks see the first failed rank's
+// status, give the call up together and return that status (the scheme of mvs_engine_exchange's status word).
+struct FilterRun {
+    mvs_engine* e;
+    int local = MVS_OK;   // first failure on this rank
+    std::string err;
+    int agreed = MVS_OK;  // != MVS_OK: the ranks have agreed to give the call up with this status
+    bool multi() const { return e->comm && e->comm_world > 1; }
+    bool live() const { return local == MVS_OK && agreed == MVS_OK; }
+    void note(int r) { if (r != MVS_OK && local == MVS_OK) { local = r; err = g_err; } }
+};
+// runs a step (an expression returning an mvs_status) unless a failure is pending
+#define FR(expr) do { if (fr.live()) fr.note(expr); } while (0)
+int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return MVS_OK;
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return MVS_ERR_HIP;
+}
+#define FRHIP(expr) FR(hip_status((expr), #expr))
+#ifdef MVS_FAULT_INJECTION
+// test builds only (libmvskit_engine_faultinj.so): MVS_FAULT_FILTER=<rank>:<point> makes that rank fail at that point of Filter::run
+void filter_fault_point(FilterRun& fr, int point) {
+    const char* f = getenv("MVS_FAULT_FILTER");
+    int r = -1, p = -1;
+    if (f && fr.live() && sscanf(f, "%d:%d", &r, &p) == 2 && r == fr.e->comm_rank && p == point) {
+        g_err = "mvs_engine_filter: failure injected by MVS_FAULT_FILTER";
+        fr.note(MVS_ERR_CAPACITY);
+    }
+}
+#else
+inline void filter_fault_point(FilterRun&, int) {}
+#endif
+// the agreement: returns MVS_OK when every rank is fine, else the status all ranks give the call up with
+int filter_agree(FilterRun& fr) {
+    mvs_engine* e = fr.e;
+    if (fr.agreed != MVS_OK) return fr.agreed;
+    if (!fr.multi()) {
+        if (fr.local != MVS_OK) { fr.agreed = fr.local; g_err = fr.err; }
+        return fr.agreed;
+    }
+    // comm_counts was sized before the first collective of the call; without it not even a status can be sent
+    const int64_t mine = fr.local;
+    std::vector<int64_t> all((size_t)e->comm_world, 0);
+    hipStream_t st = e->stream;
+    if (hipMemcpyAsync(e->comm_counts.p, &mine, sizeof mine, hipMemcpyHostToDevice, st) != hipSuccess ||
+        rccl().AllGather(e->comm_counts.p, e->comm_counts.p + 1, 1, ncclInt64, e->comm, st) != ncclSuccess ||
+        hipMemcpyAsync(all.data(), e->comm_counts.p + 1, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        g_err = "mvs_engine_filter: the status all-gather itself failed (the communicator is unusable; the job must be torn down)";
+        fr.agreed = MVS_ERR_HIP;
+        return fr.agreed;
+    }
+    for (int r = 0; r < e->comm_world; ++r) {
+        if (all[r] == MVS_OK) continue;
+        fr.agreed = (int)all[r];
+        if (r == e->comm_rank) g_err = fr.err.empty() ? std::string("mvs_engine_filter: this rank failed") : fr.err;
+        else g_err = "mvs_engine_filter: rank " + std::to_string(r) + " reported status " + std::to_string((int)all[r]) + "; all ranks give the call up";
+        break;
+    }
+    return fr.agreed;
+}
+// in-place broadcasts of every rank's share of the kill bytes and / or records (an all-gather-v without staging); returns != 0 when
+// the call is given up
+int filter_exchange(FilterRun& fr, bool kills, bool records) {
+    mvs_engine* e = fr.e;
+    if (!fr.multi()) return filter_agree(fr);
+    if (int a = filter_agree(fr)) return a;
+    if (e->pool_n == 0) return MVS_OK;
     const Rccl& R = rccl();
     hipStream_t st = e->stream;
     const int N = e->comm_world;
@@ -401,7 +488,11 @@ int filter_exchange(mvs_engine* e, bool kills, bool records) {
     }
     const ncclResult_t end = R.GroupEnd();
     if (first_err == ncclSuccess) first_err = end;
-    if (first_err != ncclSuccess) { g_err = std::string("Filter::run exchange: ") + R.GetErrorString(first_err); return MVS_ERR_HIP; }
+    if (first_err != ncclSuccess) {  // the transport itself: nothing can be agreed on any more
+        g_err = std::string("Filter::run exchange: ") + R.GetErrorString(first_err);
+        fr.note(MVS_ERR_HIP); fr.agreed = MVS_ERR_HIP;
+        return fr.agreed;
+    }
     return MVS_OK;
 }
 // Filter::filterSmallGroups with the reference's own labelling (filter.cpp:432-524; mvs_config.literal_groups): a breadth-first search
@@ -466,7 +557,7 @@ int literal_small_groups(mvs_engine* e, int threshold) {
 }
 // `incr` (after a stage's removals, marked by apply_kills): 1 = the depth maps are brought up to date in the marked cells only,
 // 2 = and so is m_vimages -- allowed when the stage removed patches and left the lists of the others alone.
-int filter_rebuild(mvs_engine* e, int additive, bool need_pgrid, bool need_vpgrid, int incr = 0) {
+int rebuild_head(mvs_engine* e, int additive, bool need_pgrid, int incr) {
     if (need_pgrid) { if (int r = build_list(e, false, false, true)) return r; }
     if (incr && e->dirty_marked) mvsk_depth_maps(current_params(e), e->dpgrid.p, e->dirty.p, e->stream);
     else { incr = 0; if (int r = build_depth(e)) return r; }
@@ -474,9 +565,19 @@ int filter_rebuild(mvs_engine* e, int additive, bool need_pgrid, bool need_vpgri
     int64_t first, last;
     filter_range(e, first, last);
     mvsk_filter_vimages(current_params(e), additive, first, last, incr == 2 && additive ? e->dirty.p : nullptr, e->stream);
-    if (int r = filter_exchange(e, false, true)) return r;  // m_vimages of the other ranks' patches
+    return MVS_OK;
+}
+int rebuild_tail(mvs_engine* e, bool need_vpgrid) {
     if (need_vpgrid) { if (int r = build_list(e, true, false, true)) return r; }
     HIPCHK(hipGetLastError());
+    return MVS_OK;
+}
+// returns != 0 when the call is given up (all ranks alike)
+int filter_rebuild(FilterRun& fr, int additive, bool need_pgrid, bool need_vpgrid, int incr = 0) {
+    FR(rebuild_head(fr.e, additive, need_pgrid, incr));
+    filter_fault_point(fr, 2);
+    if (int a = filter_exchange(fr, false, true)) return a;  // m_vimages of the other ranks' patches
+    FR(rebuild_tail(fr.e, need_vpgrid));
     return MVS_OK;
 }
 // counts and applies the kill flags a filter stage has set
@@ -495,7 +596,7 @@ int apply_kills(mvs_engine* e, int64_t* removed, bool mark = false) {
         e->dirty_marked = true;
     }
     mvsk_kill_count(e->kill.p, e->pool_n, e->kill_cnt.p, st);
-    mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, e->scan_tmp.p, st);
+    mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, reinterpret_cast<int32_t*>(e->scan_tmp.p), st);
     int32_t nk = 0;
     HIPCHK(hipMemcpyAsync(&nk, e->kill_base.p + e->pool_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     mvsk_apply_kill_flags(e->pool.p, e->kill.p, e->pool_n, st);
@@ -512,7 +613,7 @@ int ensure_counts(mvs_engine* e) {  // commit_count + scans for the staged pass
     e->h_per_view.assign(e->cfg.nviews, 0);
     if (nj > 0) {
         mvsk_commit_count(e->sa, e->job_cnt.p, st);
-        mvsk_exclusive_scan(e->job_cnt.p, e->job_base_scan.p, nj, e->scan_tmp.p, st);
+        mvsk_exclusive_scan(e->job_cnt.p, e->job_base_scan.p, nj, reinterpret_cast<int32_t*>(e->scan_tmp.p), st);
         std::vector<int32_t> bounds(e->sa.nsweep_views + 1);
         for (int s = 0; s < e->sa.nsweep_views; ++s)
             HIPCHK(hipMemcpyAsync(&bounds[s], e->job_base_scan.p + e->sa.job_base[s], sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -523,7 +624,7 @@ int ensure_counts(mvs_engine* e) {  // commit_count + scans for the staged pass
     }
     if (e->pool_n > 0) {
         mvsk_kill_count(e->kill.p, e->pool_n, e->kill_cnt.p, st);
-        mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, e->scan_tmp.p, st);
+        mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, reinterpret_cast<int32_t*>(e->scan_tmp.p), st);
         int32_t nk = 0;
         HIPCHK(hipMemcpyAsync(&nk, e->kill_base.p + e->pool_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -539,7 +640,7 @@ int compact_pool(mvs_engine* e) {
     hipStream_t st = e->stream;
     if (e->pool_n == 0) return MVS_OK;
     mvsk_alive_count(e->pool.p, e->pool_n, e->kill_cnt.p, st);
-    mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, e->scan_tmp.p, st);
+    mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, reinterpret_cast<int32_t*>(e->scan_tmp.p), st);
     int32_t alive = 0;
     HIPCHK(hipMemcpyAsync(&alive, e->kill_base.p + e->pool_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -617,7 +718,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
     e->uf_parent.release(); e->uf_size.release(); e->group_edges.release(); e->dirty.release();
-    e->vcursor.release(); e->vids.release(); e->fat.release(); e->vfat.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
+    e->vcursor.release(); e->key.release(); e->fat.release(); e->vfat.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
     e->big_tables.release(); e->retry_jobs.release();
@@ -696,9 +797,17 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
     int64_t pool_cap = e->cfg.max_patches > 0 ? e->cfg.max_patches : 4 * nc;
     if (e->cfg.max_patches <= 0) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
             pool_cap = std::max<int64_t>(std::min<int64_t>(pool_cap, (int64_t)(total_b / 6 / sizeof(DPatch))), std::min<int64_t>(pool_cap, nc));
+            // ... and, on a card that is not empty (several ranks on one GPU in a rehearsal, another process, a second engine), no more
+            // than fits what is free now: the pool-sized buffers below take 2.5 records + 17 bytes per patch, and the index comes on
+            // top.  Ranks that arrive at different capacities this way are settled in mvs_engine_exchange (minimum headroom).
+            const double per_patch = 2.5 * (double)sizeof(DPatch) + 17.0;
+            const int64_t fit = (int64_t)(0.6 * (double)free_b / per_patch);
+            if (fit < pool_cap) pool_cap = std::max<int64_t>(fit, std::min<int64_t>(pool_cap, nc / 4 + 1024));
+        }
     }
+    e->ids.headroom = e->fat.headroom = e->vfat.headroom = e->key.headroom = e->id32.headroom = e->vid32.headroom = true;
     if (e->pool.ensure(pool_cap) || e->pool_alt.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;
     HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)pool_cap, st));
     // jobs of one colour pass over every view (upper bound, used to size the staging bookkeeping)
@@ -802,8 +911,12 @@ int mvs_engine_reserve(mvs_engine* e, int64_t list_entries) {
     if (!e || !e->have_views || list_entries < 0) { g_err = "mvs_engine_reserve: views not set, or a negative size"; return MVS_ERR_ARG; }
     HIPCHK(hipSetDevice(e->cfg.device));
     int64_t n = list_entries > 0 ? list_entries : e->total_cells * (int64_t)(e->cfg.max_propag * e->cfg.csize * e->cfg.csize);
+#if MVS_FAT_INDEX
     n = std::min<int64_t>(n, (int64_t)INT32_MAX - 64);
-    if (e->ids.ensure(n + 16) || e->vids.ensure(n + 16) || e->fat.ensure(n + 16) || e->vfat.ensure(n + 16) || e->id32.ensure(n + 16) || e->vid32.ensure(n + 16)) return MVS_ERR_HIP;
+    if (e->ids.ensure(n + 16) || e->fat.ensure(n + 16) || e->vfat.ensure(n + 16) || e->id32.ensure(n + 16) || e->vid32.ensure(n + 16)) return MVS_ERR_HIP;
+#else
+    if (e->ids.ensure(n + 16) || e->key.ensure(n + 16) || e->id32.ensure(n + 16) || e->vid32.ensure(n + 16)) return MVS_ERR_HIP;
+#endif
     return MVS_OK;
 }
 
@@ -821,7 +934,7 @@ int mvs_engine_num_patches(mvs_engine* e, int64_t* n_alive) {
     *n_alive = 0;
     if (e->pool_n == 0) return MVS_OK;
     mvsk_alive_count(e->pool.p, e->pool_n, e->kill_cnt.p, e->stream);
-    mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, e->scan_tmp.p, e->stream);
+    mvsk_exclusive_scan(e->kill_cnt.p, e->kill_base.p, e->pool_n, reinterpret_cast<int32_t*>(e->scan_tmp.p), e->stream);
     int32_t tot = 0;
     HIPCHK(hipMemcpyAsync(&tot, e->kill_base.p + e->pool_n, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -900,7 +1013,7 @@ static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
             int shift = 0;  // the scan is 32-bit: scale the proxy down if its worst case would not fit
             while ((((int64_t)3 * e->prm.cap * e->prm.max_propag * 32 * nj) >> shift) >= (int64_t)INT32_MAX) ++shift;
             mvsk_job_work(p0, a, split_mode, shift, e->job_cnt.p, st);
-            mvsk_exclusive_scan(e->job_cnt.p, e->job_base_scan.p, nj, e->scan_tmp.p, st);
+            mvsk_exclusive_scan(e->job_cnt.p, e->job_base_scan.p, nj, reinterpret_cast<int32_t*>(e->scan_tmp.p), st);
             if (int r = e->tmp_i.ensure(N + 1)) return r;
             HIPCHK(hipMemsetAsync(e->tmp_i.p, 0xff, (size_t)(N + 1) * sizeof(int32_t), st));
             mvsk_job_cuts(e->job_base_scan.p, nj, N, e->tmp_i.p, st);
@@ -978,6 +1091,7 @@ static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
 #endif
     // Fault injection: MVS_FAULT_PASS=<shard>:<iter>:<pass> makes that one pass of that shard report a
     // capacity failure after its sweep, once -- how the tests drive a rank-local failure through the collective status word.
+#ifdef MVS_FAULT_INJECTION  // test builds only (libmvskit_engine_faultinj.so, mvskit_amd/build.py): the product library never reads the variable
     if (const char* f = getenv("MVS_FAULT_PASS")) {
         int fr = -1, fi = -1, fp = -1;
         if (!e->fault_fired && sscanf(f, "%d:%d:%d", &fr, &fi, &fp) == 3 && fr == (e->cfg.shard_count > 1 ? e->cfg.shard_index : 0) && fi == iter && fp == pass) {
@@ -986,6 +1100,7 @@ static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
             return MVS_ERR_CAPACITY;
         }
     }
+#endif
     if (herr & 3) { g_err = "mvs_engine_pass: staging capacity exceeded (raise mvs_config.max_patches)"; return MVS_ERR_CAPACITY; }
     if (herr & 4) {
         g_err = "mvs_engine_pass: Optim::check met more than 14336 patches around one patch, or more than 4064 neighbours (engine limit)";
@@ -1123,12 +1238,24 @@ int mvs_engine_exchange(mvs_engine* e) {
     // the evicted ids of all ranks (a rank evicts pool patches from its own cells only, but a patch sits in the cells of several
     // views, so the union may name an id twice): one allocation of pool-capacity ids, the limit agreed as the minimum over the ranks
     if (int r = e->comm_kill_ids.ensure(std::max<int64_t>(e->pool.cap, 1024))) fail_local(r);
-    if (!e->comm_counts.p) return MVS_ERR_HIP;  // not even the status word can be sent: nothing left to agree on
+    // The ONE way out before the first collective: no device word to put the status in (a 40-byte allocation failed).  This rank
+    // can then tell nobody anything; the other ranks wait in their all-gather until the launcher tears the job down (bench.py's
+    // spawn_ranks and torch.distributed.run both end the job when a rank exits non-zero) -- INTEGRATION.md, "failures".
+    if (!e->comm_counts.p) { g_err = "mvs_engine_exchange: no device memory for the status word; the job must be torn down by its launcher"; return MVS_ERR_HIP; }
     if (local != MVS_OK) { e->n_new = 0; e->n_kill = 0; }
-    // (1) one all-gather of MVS_XCHG_WORDS int64 per rank
-    const int64_t mine[MVS_XCHG_WORDS] = {e->n_new, e->n_kill, (int64_t)local, e->pool.cap - e->pool_n, e->comm_kill_ids.cap};
+    // (1) one all-gather of MVS_XCHG_WORDS int64 per rank.  A failure of the host-to-device copy of this rank's words does not skip
+    // the collective: the status word is then written by a kernel-free fallback (hipMemsetD32Async of the status alone), so the
+    // others still see a failure and nobody waits; a failure of the all-gather or of its read-back is a failure of the transport
+    // itself -- past that nothing can be agreed on.
+    int64_t mine[MVS_XCHG_WORDS] = {e->n_new, e->n_kill, (int64_t)local, e->pool.cap - e->pool_n, e->comm_kill_ids.cap};
     std::vector<int64_t> all(MVS_XCHG_WORDS * (size_t)world);
-    HIPCHK(hipMemcpyAsync(e->comm_counts.p, mine, sizeof mine, hipMemcpyHostToDevice, st));
+    if (hipMemcpyAsync(e->comm_counts.p, mine, sizeof mine, hipMemcpyHostToDevice, st) != hipSuccess) {
+        (void)hipGetLastError();
+        g_err = "mvs_engine_exchange: host-to-device copy of the count words failed"; fail_local(MVS_ERR_HIP);
+        // {0, 0, MVS_ERR_HIP (all ones in the low word, sign-extended by the second), 0, 0}: zero the words, then the status
+        (void)hipMemsetAsync(e->comm_counts.p, 0, sizeof mine, st);
+        (void)hipMemsetD32Async((hipDeviceptr_t)(e->comm_counts.p + 2), (int)(uint32_t)MVS_ERR_HIP, 2, st);
+    }
     NCCLCHK(R.AllGather(e->comm_counts.p, e->comm_counts.p + MVS_XCHG_WORDS, MVS_XCHG_WORDS, ncclInt64, e->comm, st));
     HIPCHK(hipMemcpyAsync(all.data(), e->comm_counts.p + MVS_XCHG_WORDS, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1227,98 +1354,125 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     hipStream_t st = e->stream;
     int64_t rem[4] = {0, 0, 0, 0};
     Range rg("mvs:Filter::run");
-    HIPCHK(hipEventRecord(e->ev[0], st));
-    HIPCHK(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
-    if (e->pool_n > 0) HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));
+    FilterRun fr{e};
+    // the one thing without which a rank cannot even report a failure: the word(s) of the agreement
+    if (fr.multi()) { if (int r = e->comm_counts.ensure(MVS_XCHG_WORDS * (1 + (int64_t)e->comm_world))) return r; }
+    FRHIP(hipEventRecord(e->ev[0], st));
+    FRHIP(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
+    if (e->pool_n > 0) FRHIP(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));
     e->fstats = mvs_filter_stats{};
-    if (int r = e->fstat_buf.ensure(4096)) return r;
-    HIPCHK(hipMemsetAsync(e->fstat_buf.p, 0, 4096 * sizeof(unsigned long long), st));
-    if (int r = mvs_engine_num_patches(e, &e->fstats.patches_in)) return r;
+    FR(e->fstat_buf.ensure(4096));
+    FRHIP(hipMemsetAsync(e->fstat_buf.p, 0, 4096 * sizeof(unsigned long long), st));
+    FR(mvs_engine_num_patches(e, &e->fstats.patches_in));
     e->fstats_exchange_bytes = 0;
     int64_t first = 0, last = 0;  // this rank's share of the pool (everything on one GPU)
-    if (int r = filter_rebuild(e, 0, true, false)) return r;
-    HIPCHK(hipEventRecord(e->fev[0], st));
-    filter_range(e, first, last);
-    mvsk_filter_outside(current_params(e), e->kill.p, first, last, st);          // filterOutside
-    HIPCHK(hipEventRecord(e->fev[1], st));
-    if (int r = filter_exchange(e, true, false)) return r;
-    if (int r = apply_kills(e, &rem[0], true)) return r;
-    // a stage that removed nothing leaves the depth maps, hence m_vimages (additive pass) and both grids, as they are
-    if (rem[0] > 0) { if (int r = filter_rebuild(e, 1, false, false, 2)) return r; }
-    e->fstats.exact_patches = e->fstats.patches_in - rem[0];
-    HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
-    HIPCHK(hipEventRecord(e->fev[2], st));
-#ifdef MVS_STAGE_TIMING
-    HIPCHK(hipMemsetAsync(e->counters.p, 0, sizeof(DCounters), st));
-    filter_range(e, first, last);
-    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, e->counters.p->stage, first, last, st);
-    {
-        DCounters hc;
-        HIPCHK(hipMemcpyAsync(&hc, e->counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        static const char* nm[7] = {"wave", "frames", "sampling", "pair sums", "choice", "load", "visibility"};
-        fprintf(stderr, "[filterExact cycles]");
-        for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hc.stage[k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
-        fprintf(stderr, " (wave cycles %.3e)\n", (double)hc.stage[0]);
-    }
-#else
-    filter_range(e, first, last);
-    mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, nullptr, first, last, st);  // filterExact
-#endif
-    HIPCHK(hipEventRecord(e->fev[3], st));
-    {
-        unsigned long long ev2[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(ev2, e->misc.p + 1, sizeof ev2, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        e->fstats.exact_view_evals = (int64_t)ev2[1];
-    }
-    if (int r = filter_exchange(e, true, true)) return r;  // kill bytes + the rewritten m_images
-    if (int r = apply_kills(e, &rem[1], true)) return r;
-    if (int r = filter_rebuild(e, 1, true, true, 1)) return r;  // filterExact rewrote m_images: every patch's m_vimages is tested anew
-    e->fstats.neighbor_patches = e->fstats.exact_patches - rem[1];
-    {                                                                              // filterNeighbor(1)
-        if (e->uf_parent.ensure(e->pool.cap)) return MVS_ERR_HIP;                  // reused as the retry list
-        HIPCHK(hipMemsetAsync(e->misc.p + 4, 0, sizeof(unsigned long long), st));
-        int32_t* nretry = reinterpret_cast<int32_t*>(e->misc.p + 4);
-        HIPCHK(hipEventRecord(e->fev[4], st));
-        if (!e->lists_dense[0] || !e->lists_dense[1]) { g_err = "Filter::filterNeighbor: the grid indexes must come from a rebuild without the trim"; return MVS_ERR_ARG; }
-        filter_range(e, first, last);
-        mvsk_filter_neighbor(current_params(e), e->kill.p, e->uf_parent.p, nretry, e->error_flag.p, e->fstat_buf.p, first, last, st);
-        int32_t nr = 0;
-        HIPCHK(hipMemcpyAsync(&nr, nretry, sizeof nr, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipGetLastError());
-        e->fstats.neighbor_retried = nr;
-        mvsk_filter_neighbor_retry(current_params(e), e->kill.p, e->uf_parent.p, nr, e->error_flag.p, e->fstat_buf.p, st);
-        HIPCHK(hipGetLastError());  // a refused launch (LDS request) must not pass for "nothing to filter"
-        HIPCHK(hipEventRecord(e->fev[5], st));
-    }
-    if (int r = filter_exchange(e, true, false)) return r;
-    if (int r = apply_kills(e, &rem[2], true)) return r;
-    if (rem[2] > 0) { if (int r = filter_rebuild(e, 1, true, true, 2)) return r; }
-    {                                                                              // filterSmallGroups
-        int64_t alive = 0;
-        if (int r = mvs_engine_num_patches(e, &alive)) return r;
-        if (e->uf_parent.ensure(e->pool.cap) || e->uf_size.ensure(e->pool.cap)) return MVS_ERR_HIP;
-        const int threshold = (int)std::max<int64_t>(20, alive / 10000);
-        HIPCHK(hipEventRecord(e->fev[6], st));
-        if (!e->cfg.literal_groups) mvsk_groups(current_params(e), e->uf_parent.p, e->uf_size.p, threshold, e->kill.p, st);
-        else if (int r = literal_small_groups(e, threshold)) return r;
-        HIPCHK(hipEventRecord(e->fev[7], st));
-        if (int r = apply_kills(e, &rem[3], true)) return r;
-    }
-    if (rem[3] > 0) { if (int r = filter_rebuild(e, 1, false, false, 2)) return r; }
-    if (int r = compact_pool(e)) return r;
     int32_t herr = 0;
-    HIPCHK(hipMemcpyAsync(&herr, e->error_flag.p, sizeof herr, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(e->ev[1], st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipGetLastError());
+    // every `break` below: the ranks have agreed to give the call up (or, on one GPU, a step failed)
+    do {
+        if (filter_rebuild(fr, 0, true, false)) break;
+        FRHIP(hipEventRecord(e->fev[0], st));
+        filter_range(e, first, last);
+        if (fr.live()) mvsk_filter_outside(current_params(e), e->kill.p, first, last, st);          // filterOutside
+        FRHIP(hipEventRecord(e->fev[1], st));
+        filter_fault_point(fr, 0);
+        if (filter_exchange(fr, true, false)) break;
+        FR(apply_kills(e, &rem[0], true));
+        // a stage that removed nothing leaves the depth maps, hence m_vimages (additive pass) and both grids, as they are
+        if (rem[0] > 0) { if (filter_rebuild(fr, 1, false, false, 2)) break; }
+        e->fstats.exact_patches = e->fstats.patches_in - rem[0];
+        FRHIP(hipMemsetAsync(e->misc.p + 1, 0, 2 * sizeof(unsigned long long), st));
+        FRHIP(hipEventRecord(e->fev[2], st));
+        filter_range(e, first, last);
+#ifdef MVS_STAGE_TIMING
+        FRHIP(hipMemsetAsync(e->counters.p, 0, sizeof(DCounters), st));
+        if (fr.live()) {
+            mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, e->counters.p->stage, first, last, st);
+            DCounters hc;
+            (void)hipMemcpyAsync(&hc, e->counters.p, sizeof hc, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            static const char* nm[7] = {"wave", "frames", "sampling", "pair sums", "choice", "load", "visibility"};
+            fprintf(stderr, "[filterExact cycles]");
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hc.stage[k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
+            fprintf(stderr, " (wave cycles %.3e)\n", (double)hc.stage[0]);
+        }
+#else
+        if (fr.live()) mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, nullptr, first, last, st);  // filterExact
+#endif
+        FRHIP(hipEventRecord(e->fev[3], st));
+        {
+            unsigned long long ev2[2] = {0, 0};
+            FRHIP(hipMemcpyAsync(ev2, e->misc.p + 1, sizeof ev2, hipMemcpyDeviceToHost, st));
+            FRHIP(hipStreamSynchronize(st));
+            e->fstats.exact_view_evals = (int64_t)ev2[1];
+        }
+        filter_fault_point(fr, 1);
+        if (filter_exchange(fr, true, true)) break;  // kill bytes + the rewritten m_images
+        FR(apply_kills(e, &rem[1], true));
+        if (filter_rebuild(fr, 1, true, true, 1)) break;  // filterExact rewrote m_images: every patch's m_vimages is tested anew
+        e->fstats.neighbor_patches = e->fstats.exact_patches - rem[1];
+        {                                                                              // filterNeighbor(1)
+            FR(e->uf_parent.ensure(e->pool.cap));                                      // reused as the retry list
+            FRHIP(hipMemsetAsync(e->misc.p + 4, 0, sizeof(unsigned long long), st));
+            int32_t* nretry = reinterpret_cast<int32_t*>(e->misc.p + 4);
+            FRHIP(hipEventRecord(e->fev[4], st));
+            if (fr.live() && (!e->lists_dense[0] || !e->lists_dense[1])) { g_err = "Filter::filterNeighbor: the grid indexes must come from a rebuild without the trim"; fr.note(MVS_ERR_ARG); }
+            filter_range(e, first, last);
+            int32_t nr = 0;
+            if (fr.live()) mvsk_filter_neighbor(current_params(e), e->kill.p, e->uf_parent.p, nretry, e->error_flag.p, e->fstat_buf.p, first, last, st);
+            FRHIP(hipMemcpyAsync(&nr, nretry, sizeof nr, hipMemcpyDeviceToHost, st));
+            FRHIP(hipStreamSynchronize(st));
+            FRHIP(hipGetLastError());
+            e->fstats.neighbor_retried = nr;
+            if (fr.live()) mvsk_filter_neighbor_retry(current_params(e), e->kill.p, e->uf_parent.p, nr, e->error_flag.p, e->fstat_buf.p, st);
+            FRHIP(hipGetLastError());  // a refused launch (LDS request) must not pass for "nothing to filter"
+            FRHIP(hipEventRecord(e->fev[5], st));
+        }
+        filter_fault_point(fr, 3);
+        if (filter_exchange(fr, true, false)) break;
+        FR(apply_kills(e, &rem[2], true));
+        if (rem[2] > 0) { if (filter_rebuild(fr, 1, true, true, 2)) break; }
+        {                                                                              // filterSmallGroups (replicated: every rank on the whole pool)
+            int64_t alive = 0;
+            FR(mvs_engine_num_patches(e, &alive));
+            FR(e->uf_parent.ensure(e->pool.cap));
+            FR(e->uf_size.ensure(e->pool.cap));
+            const int threshold = (int)std::max<int64_t>(20, alive / 10000);
+            FRHIP(hipEventRecord(e->fev[6], st));
+            if (fr.live()) {
+                if (!e->cfg.literal_groups) mvsk_groups(current_params(e), e->uf_parent.p, e->uf_size.p, threshold, e->kill.p, st);
+                else fr.note(literal_small_groups(e, threshold));
+            }
+            FRHIP(hipEventRecord(e->fev[7], st));
+            FR(apply_kills(e, &rem[3], true));
+        }
+        if (rem[3] > 0) { if (filter_rebuild(fr, 1, false, false, 2)) break; }
+        FR(compact_pool(e));
+        FRHIP(hipMemcpyAsync(&herr, e->error_flag.p, sizeof herr, hipMemcpyDeviceToHost, st));
+        FRHIP(hipEventRecord(e->ev[1], st));
+        FRHIP(hipStreamSynchronize(st));
+        FRHIP(hipGetLastError());
+        if (fr.live() && (herr & 4)) {  // this rank's share met the engine's limit: every rank returns that status
+            g_err = "mvs_engine_filter: more than 14336 patches around one patch, or more than 4064 neighbours (engine limit)";
+            fr.note(MVS_ERR_CAPACITY);
+        }
+    } while (0);
+    const int status = filter_agree(fr);  // the closing agreement (one GPU: this rank's own status)
+    e->index_valid = false;
+    if (status != MVS_OK) {
+        // given up: what the unfinished stage marked is forgotten.  The stages that completed stand (on every rank alike); a stage that
+        // was under way may have rewritten the lists of this rank's share only -- after an error the caller re-uploads or stops.
+        const std::string keep = g_err;
+        if (e->kill.p && e->pool_n > 0) (void)hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+        e->dirty_marked = false;
+        g_err = keep;
+        return status;
+    }
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]);
     e->timing = mvs_timing{};
     e->timing.index_ms = ms;  // whole Filter::run
-    e->index_valid = false;
     {
         mvs_filter_stats& f = e->fstats;
         f.total_ms = ms;
@@ -1335,20 +1489,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     }
     e->fstats.exchange_bytes = e->fstats_exchange_bytes;
     if (removed4) for (int k = 0; k < 4; ++k) removed4[k] = rem[k];
-    int status = MVS_OK;
-    if (herr & 4) { g_err = "mvs_engine_filter: more than 14336 patches around one patch, or more than 4064 neighbours (engine limit)"; status = MVS_ERR_CAPACITY; }
-    if (e->comm && e->comm_world > 1) {  // a rank whose share met the engine's limit: every rank returns that status
-        if (int r = e->comm_counts.ensure(MVS_XCHG_WORDS * (1 + (int64_t)e->comm_world))) return r;
-        const int64_t mine = status;
-        std::vector<int64_t> all((size_t)e->comm_world);
-        HIPCHK(hipMemcpyAsync(e->comm_counts.p, &mine, sizeof mine, hipMemcpyHostToDevice, st));
-        NCCLCHK(rccl().AllGather(e->comm_counts.p, e->comm_counts.p + 1, 1, ncclInt64, e->comm, st));
-        HIPCHK(hipMemcpyAsync(all.data(), e->comm_counts.p + 1, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        for (int r = 0; r < e->comm_world; ++r)
-            if (all[r] != MVS_OK && status == MVS_OK) { status = (int)all[r]; g_err = "mvs_engine_filter: rank " + std::to_string(r) + " met the engine's neighbourhood limit in its share of the pool"; }
-    }
-    return status;
+    return MVS_OK;
 }
 
 int mvs_engine_filter_stats(mvs_engine* e, mvs_filter_stats* out) {

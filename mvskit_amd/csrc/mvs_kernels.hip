@@ -56,41 +56,44 @@ __global__ void k_mask_binarise(uint8_t* m, int64_t n) {  // image.cpp:170-177
     if (i < n) m[i] = m[i] > 127 ? 255 : 0;
 }
 
-// =================================================================== scan (exclusive, int32)
+// =================================================================== scan (exclusive; int32 counts in, int32 or int64 offsets out)
 #define SCAN_BLOCK 256
 #define SCAN_ITEMS 4
-__global__ void k_scan_block(const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t* __restrict__ block_sums, int64_t n_in) {
-    __shared__ int32_t s[SCAN_BLOCK];
+template <typename TI, typename TO>
+__global__ void k_scan_block(const TI* __restrict__ in, TO* __restrict__ out, TO* __restrict__ block_sums, int64_t n_in) {
+    __shared__ TO s[SCAN_BLOCK];
     const int64_t base = ((int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
-    int32_t v[SCAN_ITEMS], sum = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < n_in) ? in[base + k] : 0; sum += v[k]; }
+    TO v[SCAN_ITEMS], sum = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < n_in) ? (TO)in[base + k] : (TO)0; sum += v[k]; }
     s[threadIdx.x] = sum;
     __syncthreads();
     for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-        int32_t t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0;
+        TO t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : (TO)0;
         __syncthreads();
         s[threadIdx.x] += t;
         __syncthreads();
     }
-    int32_t excl = s[threadIdx.x] - sum;
+    TO excl = s[threadIdx.x] - sum;
     for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k <= n_in) out[base + k] = excl; excl += v[k]; }
     if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = s[threadIdx.x];
 }
-__global__ void k_scan_add(int32_t* __restrict__ out, const int32_t* __restrict__ block_offsets, int64_t n_out) {
+template <typename TO>
+__global__ void k_scan_add(TO* __restrict__ out, const TO* __restrict__ block_offsets, int64_t n_out) {
     const int64_t base = ((int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
-    const int32_t o = block_offsets[blockIdx.x];
+    const TO o = block_offsets[blockIdx.x];
     for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n_out) out[base + k] += o;
 }
-// out[i] = sum of in[0..i) for i in [0, n]; out[n] is the total (out has n+1 slots, in has n; in-place allowed).
-// tmp: block sums of every recursion level, at least n/512 + 64 ints.
-void launch_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, hipStream_t st) {
+// out[i] = sum of in[0..i) for i in [0, n]; out[n] is the total (out has n+1 slots, in has n; in-place allowed when the types agree).
+// tmp: block sums of every recursion level, at least n/512 + 64 elements of TO.
+template <typename TI, typename TO>
+void launch_exclusive_scan(const TI* in, TO* out, int64_t n, TO* tmp, hipStream_t st) {
     const int64_t per = (int64_t)SCAN_BLOCK * SCAN_ITEMS;
     const int64_t nb = (n + 1 + per - 1) / per;
-    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, out, tmp, n);
+    hipLaunchKernelGGL((k_scan_block<TI, TO>), dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, out, tmp, n);
     if (nb > 1) {
-        int32_t* tmp2 = tmp + nb + 1;
-        launch_exclusive_scan(tmp, tmp, nb, tmp2, st);
-        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, out, tmp, n + 1);
+        TO* tmp2 = tmp + nb + 1;
+        launch_exclusive_scan<TO, TO>(tmp, tmp, nb, tmp2, st);
+        hipLaunchKernelGGL((k_scan_add<TO>), dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, out, tmp, n + 1);
     }
 }
 
@@ -101,6 +104,28 @@ DEV uint32_t sortable_f32(float f) {
 // list entry of the index build: ascending key order = descending m_ncc, then ascending id (PatchManager::sortPatches)
 __device__ __forceinline__ unsigned long long list_key(float ncc, int64_t id) {
     return ((unsigned long long)(~sortable_f32(ncc + 0.0f)) << 32) | (unsigned long long)(uint32_t)id;  // + 0.0f: -0 sorts as +0
+}
+// m_pgrids entry `pos` (an offset into the index): the fields the sweep reads of its own and its source cells
+DEV int pgrid_id(const DParams& prm, csr_off_t pos) {
+#if MVS_FAT_INDEX
+    return prm.csr_fat[pos].id;
+#else
+    return prm.csr_id32[pos];
+#endif
+}
+DEV float pgrid_ncc(const DParams& prm, csr_off_t pos) {
+#if MVS_FAT_INDEX
+    return prm.csr_fat[pos].ncc;
+#else
+    return prm.csr_key[pos].ncc;
+#endif
+}
+DEV int pgrid_ref(const DParams& prm, csr_off_t pos) {
+#if MVS_FAT_INDEX
+    return prm.csr_fat[pos].ref;
+#else
+    return prm.csr_key[pos].ref;
+#endif
 }
 // =================================================================== index build
 // cnt[gcell] += 1 for every (patch, view) membership: PatchManager::addPatch, patch_manager.cpp:158-186
@@ -134,50 +159,15 @@ __global__ void k_index_count(DParams prm, int32_t* __restrict__ cnt, int32_t* _
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, (unsigned long long)mine);
 }
-__global__ void k_index_fill(DParams prm, const int32_t* __restrict__ start, int32_t* __restrict__ cursor, unsigned long long* __restrict__ ids,
-                             const int32_t* __restrict__ vstart, int32_t* __restrict__ vcursor, unsigned long long* __restrict__ vids) {
+// one grid per launch (vgrid = 0: m_pgrids from m_images, 1: m_vpgrids from m_vimages): the sort key travels with the id, the per-cell
+// sort reads no patch
+__global__ void k_index_fill(DParams prm, int vgrid, const csr_off_t* __restrict__ start, int32_t* __restrict__ cursor, unsigned long long* __restrict__ ids) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= prm.pool_n) return;
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
     const F4 coord = ld4(p->coord);
-    const unsigned long long key = list_key(p->ncc, id);  // the sort key travels with the id: the per-cell sort reads no patch
-    const int n = start ? min(p->nimages, MVS_LISTCAP) : 0;
-    for (int i = 0; i < n; ++i) {
-        const DView* vw = prm.views + p->images[i];
-        int ix, iy;
-        cell_of(prm, vw, coord, ix, iy);
-        if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
-        const int g = vw->cell_base + iy * vw->gw + ix;
-        ids[start[g] + atomicAdd(&cursor[g], 1)] = key;
-    }
-    if (vstart) {
-        const int nv = min(p->nvimages, MVS_LISTCAP);
-        for (int i = 0; i < nv; ++i) {
-            const DView* vw = prm.views + p->vimages[i];
-            int ix, iy;
-            cell_of(prm, vw, coord, ix, iy);
-            if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
-            const int g = vw->cell_base + iy * vw->gw + ix;
-            vids[vstart[g] + atomicAdd(&vcursor[g], 1)] = key;
-        }
-    }
-}
-// The index between the stages of Filter::run: no trim, and no stage depends on the order inside a list (computeGain takes maxima,
-// findNeighbors builds a set whose layout is the same for every insertion order, filterSmallGroups joins sets), so the thread that
-// holds the record writes the finished entry straight into its slot: no keys, no per-cell sort, no gather of the records.
-__global__ void k_index_fill_direct(DParams prm, int vgrid, const int32_t* __restrict__ start, int32_t* __restrict__ cursor, CellEntry* __restrict__ fat,
-                                    int32_t* __restrict__ id32) {
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= prm.pool_n) return;
-    const DPatch* p = prm.pool + id;
-    if (!(p->flags & 1)) return;
-    const F4 coord = ld4(p->coord), normal = ld4(p->normal);
-    CellEntry ce;
-    ce.id = (int32_t)id; ce.ncc = p->ncc;
-    ce.coord[0] = coord.x; ce.coord[1] = coord.y; ce.coord[2] = coord.z;
-    ce.normal[0] = normal.x; ce.normal[1] = normal.y; ce.normal[2] = normal.z;
-    ce.dscale = p->dscale; ce.ref = p->images[0]; ce.pad[0] = 0; ce.pad[1] = 0;
+    const unsigned long long key = list_key(p->ncc, id);
     const int n = vgrid ? min(p->nvimages, MVS_LISTCAP) : min(p->nimages, MVS_LISTCAP);
     for (int i = 0; i < n; ++i) {
         const DView* vw = prm.views + (vgrid ? p->vimages[i] : p->images[i]);
@@ -185,21 +175,52 @@ __global__ void k_index_fill_direct(DParams prm, int vgrid, const int32_t* __res
         cell_of(prm, vw, coord, ix, iy);
         if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
         const int g = vw->cell_base + iy * vw->gw + ix;
-        const int slot = start[g] + atomicAdd(&cursor[g], 1);
+        ids[start[g] + atomicAdd(&cursor[g], 1)] = key;
+    }
+}
+// The index between the stages of Filter::run: no trim, and no stage depends on the order inside a list (computeGain takes maxima,
+// findNeighbors builds a set whose layout is the same for every insertion order, filterSmallGroups joins sets), so the thread that
+// holds the record writes the finished entry straight into its slot: no keys, no per-cell sort, no gather of the records.
+// (Slim index: the entry is the id; no reader inside Filter::run looks at csr_key.)
+__global__ void k_index_fill_direct(DParams prm, int vgrid, const csr_off_t* __restrict__ start, int32_t* __restrict__ cursor, CellEntry* __restrict__ fat,
+                                    int32_t* __restrict__ id32) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= prm.pool_n) return;
+    const DPatch* p = prm.pool + id;
+    if (!(p->flags & 1)) return;
+    const F4 coord = ld4(p->coord);
+#if MVS_FAT_INDEX
+    const F4 normal = ld4(p->normal);
+    CellEntry ce;
+    ce.id = (int32_t)id; ce.ncc = p->ncc;
+    ce.coord[0] = coord.x; ce.coord[1] = coord.y; ce.coord[2] = coord.z;
+    ce.normal[0] = normal.x; ce.normal[1] = normal.y; ce.normal[2] = normal.z;
+    ce.dscale = p->dscale; ce.ref = p->images[0]; ce.pad[0] = 0; ce.pad[1] = 0;
+#endif
+    const int n = vgrid ? min(p->nvimages, MVS_LISTCAP) : min(p->nimages, MVS_LISTCAP);
+    for (int i = 0; i < n; ++i) {
+        const DView* vw = prm.views + (vgrid ? p->vimages[i] : p->images[i]);
+        int ix, iy;
+        cell_of(prm, vw, coord, ix, iy);
+        if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
+        const int g = vw->cell_base + iy * vw->gw + ix;
+        const csr_off_t slot = start[g] + atomicAdd(&cursor[g], 1);
+#if MVS_FAT_INDEX
         fat[slot] = ce;
+#endif
         id32[slot] = (int32_t)id;
     }
 }
 // PatchManager::sortPatches (descending NCC; ties by id) per cell, then the MAX_NUM_OF_PATCHES trim
 // (propagate.cpp:94-99,130-135): every cell decides on the same snapshot; a trimmed patch dies everywhere.
-__global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start, unsigned long long* __restrict__ ids, int do_trim,
+__global__ void k_index_sort_trim(DParams prm, const csr_off_t* __restrict__ start, unsigned long long* __restrict__ ids, int do_trim,
                                   unsigned long long* __restrict__ trimmed) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = g < prm.total_cells;
-    const int b = in ? start[g] : 0, e = in ? start[g + 1] : 0;
-    for (int i = b + 1; i < e; ++i) {  // insertion sort, ascending keys
+    const csr_off_t b = in ? start[g] : 0, e = in ? start[g + 1] : 0;
+    for (csr_off_t i = b + 1; i < e; ++i) {  // insertion sort, ascending keys
         const unsigned long long k = ids[i];
-        int j = i - 1;
+        csr_off_t j = i - 1;
         while (j >= b) {
             const unsigned long long o = ids[j];
             if (o < k) break;
@@ -210,7 +231,7 @@ __global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start
     }
     if (do_trim) {
         int mine = 0;
-        for (int k = b + prm.cap; k < e; ++k) {
+        for (csr_off_t k = b + prm.cap; k < e; ++k) {
             const int old = atomicAnd(&prm.pool[(uint32_t)ids[k]].flags, ~1);
             mine += old & 1;
         }
@@ -219,23 +240,27 @@ __global__ void k_index_sort_trim(DParams prm, const int32_t* __restrict__ start
         if ((threadIdx.x & 63) == 0 && mine) atomicAdd(trimmed, (unsigned long long)mine);
     }
 }
-// After the trim: every list is compacted to its alive entries (order kept) and written out "fat".
-__global__ void k_index_finalize(DParams prm, const int32_t* __restrict__ start, const unsigned long long* __restrict__ ids, CellEntry* __restrict__ fat,
-                                 int32_t* __restrict__ id32, int32_t* __restrict__ cnt_alive) {
+// After the trim: every list is compacted to its alive entries (order kept) and written out -- "fat", or as (id, ListKey).
+__global__ void k_index_finalize(DParams prm, int vgrid, const csr_off_t* __restrict__ start, const unsigned long long* __restrict__ ids, CellEntry* __restrict__ fat,
+                                 ListKey* __restrict__ key, int32_t* __restrict__ id32, int32_t* __restrict__ cnt_alive) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= prm.total_cells) return;
-    const int b = start[g], e = start[g + 1];
+    const csr_off_t b = start[g], e = start[g + 1];
     int n = 0;
-    for (int k = b; k < e; ++k) {
+    for (csr_off_t k = b; k < e; ++k) {
         const int id = (int)(uint32_t)ids[k];
         const DPatch* p = prm.pool + id;
         if (!(p->flags & 1)) continue;
+#if MVS_FAT_INDEX
         CellEntry ce;
         ce.id = id; ce.ncc = p->ncc;
         ce.coord[0] = p->coord[0]; ce.coord[1] = p->coord[1]; ce.coord[2] = p->coord[2];
         ce.normal[0] = p->normal[0]; ce.normal[1] = p->normal[1]; ce.normal[2] = p->normal[2];
         ce.dscale = p->dscale; ce.ref = p->images[0]; ce.pad[0] = 0; ce.pad[1] = 0;
         fat[b + n] = ce;
+#else
+        if (!vgrid) { ListKey lk; lk.ncc = p->ncc; lk.ref = p->images[0]; key[b + n] = lk; }  // m_vpgrids' readers want ids only
+#endif
         id32[b + n] = id;
         ++n;
     }
@@ -385,9 +410,9 @@ __global__ void k_job_work(DParams prm, SweepArgs a, int mode, int shift, int32_
         for (int k = 0; k < nsrc; ++k) {
             if (sxs[k] < 0 || gw <= sxs[k] || sys[k] < 0 || gh <= sys[k]) continue;
             const int g = vw->cell_base + sys[k] * gw + sxs[k];
-            const CellEntry* se = prm.csr_fat + prm.csr_start[g];
+            const csr_off_t sb = prm.csr_start[g];
             const int sn = prm.csr_cnt[g];
-            for (int j = 0; j < sn; ++j) n += ((se[j].ref == v) != (k == 2)) ? 1 : 0;
+            for (int j = 0; j < sn; ++j) n += ((pgrid_ref(prm, sb + j) == v) != (k == 2)) ? 1 : 0;
         }
         if (mode == 1) w = n;
         else {
@@ -469,9 +494,9 @@ DEV void sweep_cell(const DParams& prm, const SweepArgs& a, const int64_t job, i
     int L_n = 0;
     {
         const int g = vw->cell_base + cell;
-        const CellEntry* fe = prm.csr_fat + prm.csr_start[g];
+        const csr_off_t fb = prm.csr_start[g];
         L_n = min(prm.csr_cnt[g], MVS_CAPMAX);
-        if (wc.lane < L_n) { L_id = fe[wc.lane].id; L_ncc = fe[wc.lane].ncc; }
+        if (wc.lane < L_n) { L_id = pgrid_id(prm, fb + wc.lane); L_ncc = pgrid_ncc(prm, fb + wc.lane); }
     }
     int ns = 0;  // staged records of this job
     bool gave_up = false;
@@ -485,12 +510,19 @@ DEV void sweep_cell(const DParams& prm, const SweepArgs& a, const int64_t job, i
         const int scx = sidx < 2 ? sxs[sidx] : cx, scy = sidx < 2 ? sys[sidx] : cy;
         if (scx < 0 || gw <= scx || scy < 0 || gh <= scy) continue;
         const int g = vw->cell_base + scy * gw + scx;
-        const CellEntry* se = prm.csr_fat + prm.csr_start[g];
-        const int sn = prm.csr_cnt[g];
+        const csr_off_t sb = prm.csr_start[g];
+        const int sn = min(prm.csr_cnt[g], MVS_CAPMAX);  // a trimmed list: at most MAX_NUM_OF_PATCHES <= 32 entries
         const int as_view = sidx == 2 ? v : -1;
-        for (int n = 0; n < sn; ++n) {
-            if ((se[n].ref == v) == (sidx == 2)) continue;
-            const DPatch* sp = prm.pool + se[n].id;
+        // the entries of the source list, a lane each, in ONE round trip (the walk used to read entry after entry: a dependent load
+        // per entry, six in seven of them only to find another reference view); then the sources in list order
+        int E_id = 0;
+        bool E_take = false;
+        if (wc.lane < sn) { E_id = pgrid_id(prm, sb + wc.lane); E_take = (pgrid_ref(prm, sb + wc.lane) == v) != (sidx == 2); }
+        unsigned todo = (unsigned)ballot(E_take);
+        while (todo) {
+            const int n = __ffs((int)todo) - 1;
+            todo &= todo - 1u;
+            const DPatch* sp = prm.pool + rli(E_id, n);
             const int srcslot = sidx * prm.cap + n;
             // ---- Propagate::propagatePatch, propagate.cpp:153-213
             for (int it = 0; it < prm.max_propag; ++it) {
@@ -992,7 +1024,8 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
     int gx, gy;
     cell_of(prm, vw, me.coord, gx, gy);
     // lane l < 18: list l = (kind, dy, dx); its start and length, and the running total before it
-    int lstart = 0, ln = 0;
+    csr_off_t lstart = 0;
+    int ln = 0;
     if (lane < 18) {
         const int kind = lane / 9, yt = gy + (lane % 9) / 3 - 1, xt = gx + lane % 3 - 1;
         if (!(yt < 0 || vw->gh <= yt || xt < 0 || vw->gw <= xt)) {
@@ -1012,9 +1045,14 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
         int lo = 0;
 #pragma unroll
         for (int step = 16; step >= 1; step >>= 1) { const int pc = __shfl(before, lo + step); if (pc <= k) lo += step; }
-        const int l_first = __shfl(before, lo), l_start = __shfl(lstart, lo);
+        const int l_first = __shfl(before, lo);
+        const csr_off_t l_start = __shfl(lstart, lo);
         if (k >= total) return false;
+#if MVS_FAT_INDEX
         e = (lo >= 9 ? prm.vcsr_fat : prm.csr_fat)[l_start + (k - l_first)];
+#else
+        e.id = (lo >= 9 ? prm.vcsr_id32 : prm.csr_id32)[l_start + (k - l_first)];  // the slim index lists ids; edge() fetches the rest from the record
+#endif
         return true;
     };
     auto edge = [&](const CellEntry& e) {
@@ -1022,12 +1060,16 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
         // two patches that hang on the same node are in one set already: one load instead of the predicate and the two root searches
         // of a union -- the common case once the large component has formed and its paths are short
         if (MODE != 2 && __atomic_load_n(&parent[e.id], __ATOMIC_RELAXED) == __atomic_load_n(&parent[id], __ATOMIC_RELAXED)) return;
+#if MVS_FAT_INDEX
         const PGeo q{{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
+#else
+        const PGeo q = load_geo(prm.pool + e.id);  // only for the entries the same-set test lets through
+#endif
         if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) return;
         if (MODE == 0) uf_union(parent, (int)id, e.id);
         else if (MODE == 1) {
-            if (!((listed >> e.ref) & 1ull)) return;
-            const DView* qw = prm.views + e.ref;
+            if (!((listed >> q.ref) & 1ull)) return;
+            const DView* qw = prm.views + q.ref;
             int px, py, qx, qy;
             cell_of(prm, qw, me.coord, px, py);
             cell_of(prm, qw, q.coord, qx, qy);
@@ -1141,21 +1183,23 @@ void mvsk_mask_down(const uint8_t* src, int pw, int ph, uint8_t* dst, int w, int
     hipLaunchKernelGGL(k_mask_down, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, st, src, pw, ph, dst, w, h);
 }
 void mvsk_mask_binarise(uint8_t* m, int64_t n, hipStream_t st) { hipLaunchKernelGGL(k_mask_binarise, dim3(nblk(n, 256)), dim3(256), 0, st, m, n); }
-void mvsk_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, hipStream_t st) { launch_exclusive_scan(in, out, n, tmp, st); }
+void mvsk_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, hipStream_t st) { launch_exclusive_scan<int32_t, int32_t>(in, out, n, tmp, st); }
+// the per-cell counts -> list offsets (32-bit in the fat index, 64-bit in the slim one); tmp as above, in elements of csr_off_t
+void mvsk_exclusive_scan_off(const int32_t* in, csr_off_t* out, int64_t n, csr_off_t* tmp, hipStream_t st) { launch_exclusive_scan<int32_t, csr_off_t>(in, out, n, tmp, st); }
 void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, unsigned long long* total, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, cnt, vcnt, total);
 }
-void mvsk_index_fill(const DParams& prm, const int32_t* start, int32_t* cursor, unsigned long long* ids, const int32_t* vstart, int32_t* vcursor, unsigned long long* vids, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, start, cursor, ids, vstart, vcursor, vids);
+void mvsk_index_fill(const DParams& prm, int vgrid, const csr_off_t* start, int32_t* cursor, unsigned long long* ids, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, vgrid, start, cursor, ids);
 }
-void mvsk_index_fill_direct(const DParams& prm, int vgrid, const int32_t* start, int32_t* cursor, CellEntry* fat, int32_t* id32, hipStream_t st) {
+void mvsk_index_fill_direct(const DParams& prm, int vgrid, const csr_off_t* start, int32_t* cursor, CellEntry* fat, int32_t* id32, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill_direct, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, vgrid, start, cursor, fat, id32);
 }
-void mvsk_index_sort_trim(const DParams& prm, const int32_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
+void mvsk_index_sort_trim(const DParams& prm, const csr_off_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
     hipLaunchKernelGGL(k_index_sort_trim, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, do_trim, trimmed);
 }
-void mvsk_index_finalize(const DParams& prm, const int32_t* start, const unsigned long long* ids, CellEntry* fat, int32_t* id32, int32_t* cnt_alive, hipStream_t st) {
-    hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, fat, id32, cnt_alive);
+void mvsk_index_finalize(const DParams& prm, int vgrid, const csr_off_t* start, const unsigned long long* ids, CellEntry* fat, ListKey* key, int32_t* id32, int32_t* cnt_alive, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, vgrid, start, ids, fat, key, id32, cnt_alive);
 }
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, const uint32_t* dirty, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_depth_maps, dim3(nblk(prm.pool_n, 64)), dim3(256), 0, st, prm, dp, dirty);

@@ -30,9 +30,23 @@ struct DPatch {
 static_assert(sizeof(DPatch) == 64 + 2 * MVS_MAXI, "record is 128 bytes (192 in the 64-view build)");
 #define MVS_REC_U4 (sizeof(DPatch) / 16)  // a record as 16-byte words
 
-// Entry of a cell list in the per-pass index: the patch id plus the fields the list consumers need (sort key,
-// reference view, and the geometry of PmMvps::isNeighbor*), so that walking a list is one contiguous stream
-// instead of a dependent load into the pool per entry.  48 bytes.
+// The cell index (PatchManager::m_pgrids / m_vpgrids as lists, patch_manager.hpp:90-104) comes in two forms, chosen at build time:
+//   MVS_FAT_INDEX 1 (the 16- and 32-view builds): per membership a 48-byte CellEntry -- the patch id plus the fields the list
+//     consumers need (sort key, reference view, the geometry of PmMvps::isNeighbor*) -- so that walking a list is one contiguous
+//     stream instead of a dependent load into the pool per entry, the ids alone again as a compact int32 array, 32-bit offsets:
+//     60 bytes per membership with the sort keys, patches x views per patch < 2^31;
+//   MVS_FAT_INDEX 0 (the 64-view build; any build with -DMVS_FAT_INDEX=0): per membership the 4-byte id, for m_pgrids also an 8-byte
+//     ListKey (m_ncc and the reference view: what the sweep reads of its own and its source cells), 64-bit offsets; the geometry of a
+//     listed patch comes from its pool record (one cache line).  12 bytes per membership with the transient sort keys (one buffer
+//     serves both grids), no 2^31 limit: what a 48-view data set needs, whose patches sit in 20-40 lists each.
+#ifndef MVS_FAT_INDEX
+#define MVS_FAT_INDEX (MVS_LISTCAP <= 32)
+#endif
+#if MVS_FAT_INDEX
+typedef int32_t csr_off_t;
+#else
+typedef int64_t csr_off_t;
+#endif
 struct CellEntry {
     int32_t id;
     float ncc;
@@ -43,6 +57,11 @@ struct CellEntry {
     int32_t pad[2];
 };
 static_assert(sizeof(CellEntry) == 48, "cell entry is 48 bytes");
+struct ListKey {
+    float ncc;
+    int32_t ref;
+};
+static_assert(sizeof(ListKey) == 8, "list key is 8 bytes");
 
 // One view resident in HBM: camera (image/camera.cpp:65-100), Optim axes (optim.cpp:43-65), pyramid
 // (image/image.cpp:245-315) as RGBA8 texels (one 32-bit load per texel), mask at m_level, grid size.
@@ -76,15 +95,16 @@ struct DParams {
     const DView* views;
     DPatch* pool;
     int64_t pool_n;
-    // index (rebuilt every pass): per concatenated cell [start, start+cnt) into csr_ids, sorted (ncc desc, id asc)
-    // cell g: entries csr_fat[csr_start[g] .. + csr_cnt[g]) -- alive patches only, sorted (ncc desc, id asc)
-    const int32_t* csr_start;
+    // index (rebuilt every pass): cell g holds entries [csr_start[g], csr_start[g] + csr_cnt[g]) -- alive patches only, m_pgrids sorted
+    // (ncc desc, id asc) in Propagate::run
+    const csr_off_t* csr_start;
     const int32_t* csr_cnt;
-    const CellEntry* csr_fat;
-    const int32_t* csr_id32;   // the ids alone, parallel to csr_fat: findNeighbors' first phase walks ids only (4 B instead of a 48-B entry per patch met)
-    const int32_t* vcsr_start;
+    const CellEntry* csr_fat;  // MVS_FAT_INDEX only
+    const ListKey* csr_key;    // !MVS_FAT_INDEX only: (m_ncc, reference view), parallel to csr_id32; valid after a Propagate::run index build
+    const int32_t* csr_id32;   // the ids alone: findNeighbors' first phase walks ids only (4 B per patch met)
+    const csr_off_t* vcsr_start;
     const int32_t* vcsr_cnt;
-    const CellEntry* vcsr_fat;
+    const CellEntry* vcsr_fat; // MVS_FAT_INDEX only
     const int32_t* vcsr_id32;
     const unsigned long long* dpgrid;  // (sortable depth << 32 | id), ~0ull = m_MAXDEPTH
 };

@@ -615,6 +615,13 @@ int PmMvps::createEngine(float maxAngle, float quad) {
              << " views per patch list: use the host library built for the larger engine (cap32: up to 32 views, cap64: up to 64)" << endl;
         if (m_strictListCap) return MVS_ERR_ARG;
     }
+    // three engine libraries export the same symbols with two record widths: a host library that resolved against the wrong one
+    // (LD_PRELOAD, load order, rpath) would corrupt records silently on upload and download
+    if (mvs_patch_bytes() != (int)sizeof(mvs_patch)) {
+        cerr << "PmMvps::init: the loaded engine library has " << mvs_patch_bytes() << "-byte patch records, this host library was built for "
+             << sizeof(mvs_patch) << " (MVS_MAX_IMAGES " << MVS_MAX_IMAGES << "): wrong libmvskit_engine*.so resolved" << endl;
+        return MVS_ERR_ARG;
+    }
     int r = mvs_engine_create(&cfg, &m_engine);
     if (r != 0) { cerr << "PmMvps::init: " << mvs_last_error() << endl; return r; }
     vector<mvs_view_desc> views(m_nimages);
@@ -647,6 +654,21 @@ long long wall_ns() { return (long long)std::chrono::duration_cast<std::chrono::
 int PmMvps::joinRanks() {
     if (m_commIdFile.empty()) return 0;
     if (m_jobNonce == 0) { if (const char* n = getenv("MVS_JOB_NONCE")) m_jobNonce = std::strtoull(n, nullptr, 0); }
+    // no explicit nonce: whatever the launcher gives every rank of ONE job and changes from job to job -- torchrun's run id, a
+    // scheduler's job id, the rendezvous port (hashed; the age test below stays the last resort for bare launches)
+    if (m_jobNonce == 0 && m_world > 1) {
+        const char* keys[] = {"TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PBS_JOBID", "LSB_JOBID", "MASTER_PORT"};
+        unsigned long long h = 1469598103934665603ull;  // FNV-1a over "key=value" of the ones present
+        bool any = false;
+        for (const char* k : keys) {
+            const char* v = getenv(k);
+            if (!v || !*v) continue;
+            any = true;
+            for (const char* c = k; *c; ++c) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+            for (const char* c = v; *c; ++c) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+        }
+        if (any) m_jobNonce = h | 1ull;
+    }
     IdFile f;
     memset(&f, 0, sizeof f);
     if (m_rank == 0) {

@@ -170,8 +170,13 @@ def _worker_failing_rank(rank, world, out_dir, mode):
 
     sys.path.insert(0, ROOT)
     os.environ["MVS_CCL_LIBRARY"] = LOOPBACK_LIB
+    from mvskit_amd import build
     if mode == "fault":
         os.environ["MVS_FAULT_PASS"] = "1:1:0"
+    if mode.startswith("filter"):
+        os.environ["MVS_FAULT_FILTER"] = "1:" + mode[len("filter"):]
+    if mode != "pool":  # the hooks exist only in the test build of the engine (-DMVS_FAULT_INJECTION)
+        os.environ["MVS_ENGINE_LIB"] = build.build_engine(fault_injection=True)
     from mvskit_amd import engine
 
     sc, seeds = _scene()
@@ -202,10 +207,33 @@ def _worker_failing_rank(rank, world, out_dir, mode):
                 log.append((it, 0, c["patches"]))
             else:
                 break
+        if mode.startswith("filter"):  # Filter::run after every iteration; rank 1 fails inside the first one
+            try:
+                e.filter()
+                log.append((it, 0, -1))
+            except engine.EngineError as err:
+                log.append((it, err.status, -1))
+                break
         e.update_threshold()
     np.save(os.path.join(out_dir, f"fail_log_{rank}.npy"), np.array(log, dtype=np.int64))
     np.save(os.path.join(out_dir, f"fail_pool_{rank}.npy"), e.patches().view(np.uint8))
     e.comm_release()
+
+
+@pytest.mark.parametrize("point", [0, 1, 2, 3])
+def test_filter_rank_local_failure_is_agreed_by_all_ranks(tmp_path, point):
+    """The same inside the collective Filter::run: rank 1 fails on its own (MVS_FAULT_FILTER, in the test build of the engine) before the
+    exchange of filterOutside's kill bytes (0), of filterExact's rewritten records (1), inside a rebuild (2) or before filterNeighbor's
+    exchange (3).  An agreement stands in front of every collective of the call, so rank 0 -- which is fine -- learns of it at its next
+    appointment: both ranks return MVS_ERR_CAPACITY from the same mvs_engine_filter and neither waits in a broadcast (the loopback's
+    barrier would time out and the spawn fail)."""
+    import subprocess
+
+    subprocess.check_call(["make", "-C", LOOPBACK_DIR, "-s"])
+    mp.spawn(_worker_failing_rank, args=(2, str(tmp_path), f"filter{point}"), nprocs=2, join=True)
+    logs = [np.load(tmp_path / f"fail_log_{r}.npy") for r in range(2)]
+    np.testing.assert_array_equal(logs[0][:, :2], logs[1][:, :2])
+    assert logs[0].shape[0] == 2 and logs[0][0, 1] == 0 and logs[0][1, 1] == -4, logs[0]  # iteration 0 propagated, its Filter::run gave up
 
 
 @pytest.mark.parametrize("mode", ["fault", "pool"])
