@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--filter", action="store_true", help="BASELINE config 5: run Filter::run (filter.cpp:25-49) after every iteration, inside the timed region")
     ap.add_argument("--no-config5", dest="config5", action="store_false", help="skip the extra repetition with Filter::run that fills the `config5` block")
+    ap.add_argument("--no-config4", dest="config4", action="store_false", help="skip the BASELINE configs[3] block (48 views of 3840x2160, five iterations with Filter::run, the 64-view library)")
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal: run the N>1 code path (RCCL exchange) with a world of 1")
     ap.add_argument("--list-cap", type=int, default=0, help="views per m_images / m_vimages list = which engine library (16, 32, 64); 0 = the smallest that holds --views")
     ap.add_argument("--scene-cache", default=os.path.join("/tmp", "mvskit_scene_cache"))
@@ -172,6 +173,74 @@ def cpu_baseline(args, sc, seeds, pool_after_iter0, gpu_patches_by_iter):
                         "sample": f"oracle engine schedule, OpenMP over destination cells, colour pass 1 of iteration 0 until {max(1.0, args.cpu_seconds / 3):.0f} s "
                                   f"had passed: {c['patches']} patches in {spent:.1f} s"}
     return res
+
+
+def run_config4(log_fn):
+    """BASELINE configs[3] on ONE MI355X: 48 views of 3840x2160 (99.5 M cells of 2x2 pixels), the 64-view library (no list is cut),
+    seeds in ALL cells' neighbourhoods of ALL views (one per 4x4 cells: 6.2 M), and the five iterations of PmMvps::run's loop
+    (pmmvps.cpp:90-110): Propagate::run, Filter::run, updateThreshold, ++m_depth.  Its own scene, engine and clock; the clock runs
+    around the five (Propagate::run + Filter::run) pairs, inputs resident."""
+    import numpy as np
+    import torch
+
+    from mvskit_amd import engine as eng
+    from mvskit_amd import synth
+
+    t0 = time.perf_counter()
+    sc = synth.make_scene(nviews=48, W=3840, H=2160, arc_deg=110.0, radius=4.0, kind="multi")
+    seeds = synth.make_seeds(sc, level=0, csize=2, stride=4, seed=777)
+    sc.points = None
+    sc.normals = None
+    t_scene = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    free0, total_mem = torch.cuda.mem_get_info()
+    max_patches = 128_000_000
+    e = eng.Engine(48, level=0, csize=2, wsize=7, minImageNum=3, enable_check=1, seed=1, nccThreshold=NCC0, depth=DEPTH0, max_patches=max_patches)
+    e.set_scene(sc)
+    e.upload_patches(seeds)
+    torch.cuda.synchronize()
+    log_fn(f"config4: scene + seeds in {t_scene:.0f} s, {seeds.shape[0]} seeds, list_cap {e.list_cap}")
+    its = []
+    patches = view_evals = 0
+    sweep_ms = index_ms = commit_ms = filter_ms = 0.0
+    launches = 0
+    peak = 0.0
+    timed = 0.0
+    for it in range(5):
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        c = e.propagate(it)
+        t = e.timing()
+        tb = time.perf_counter()
+        removed = e.filter()
+        fs = e.filter_stats()
+        e.update_threshold()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        timed += tc - ta
+        free1, _ = torch.cuda.mem_get_info()
+        peak = max(peak, (free0 - free1) / 2 ** 30)
+        patches += c["patches"]; view_evals += c["view_evals"]
+        sweep_ms += t["sweep_ms"]; index_ms += t["index_ms"]; commit_ms += t["commit_ms"]; launches += t["sweep_launches"]; filter_ms += fs["total_ms"]
+        alive = e.num_patches()
+        its.append({"iteration": it, "patches": c["patches"], "inserted": c["inserted"], "replaced": c["replaced"], "trimmed": c["trimmed"], "check_rejected_or_failed": c["fail1"],
+                    "propagate_ms": 1000.0 * (tb - ta), "sweep_ms": t["sweep_ms"], "index_ms": t["index_ms"], "filter_ms": fs["total_ms"], "filter_removed": removed,
+                    "pool_alive": alive, "hbm_used_GiB": (free0 - free1) / 2 ** 30, "check_retried_cells": t["check_retried_cells"]})
+        log_fn(f"config4 iter {it}: {its[-1]}")
+    e.close()
+    alg = view_evals * ALG_BYTES_PER_VIEW_EVAL
+    ach = alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    return {"workload": "BASELINE configs[3] on one GPU: 48 views of 3840x2160 on the 110 degree arc (99.5 M cells), level 0, csize 2, wsize 7, minImageNum 3, the 64-view "
+                        "library (192-byte records, no list cut), 1 seed per 4x4 cells over ALL cells of ALL 48 views; the five iterations of PmMvps::run's loop: "
+                        "Propagate::run + Filter::run + updateThreshold + ++m_depth (Optim::check from the second), timed together, inputs resident",
+            "metric": "patches/s (propagate+optim iteration + Filter::run), 48-view 4K", "value": patches / timed if timed > 0 else 0.0, "unit": "patches/s",
+            "steps": 5, "ms_per_step": 1000.0 * timed / 5, "patches": patches, "view_evals": view_evals, "seeds": int(seeds.shape[0]), "max_patches": max_patches,
+            "list_cap": 64, "record_bytes": 192, "cells": 48 * 1920 * 1080, "hbm_peak_GiB": peak, "hbm_total_GiB": total_mem / 2 ** 30,
+            "propagate_only_value": patches / ((sweep_ms + index_ms + commit_ms) * 1e-3) if sweep_ms > 0 else 0.0,
+            "filter_ms_per_call": filter_ms / 5, "index_ms_per_step": index_ms / 5, "scene_generation_s": t_scene,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_sweep (64-view build)",
+                         "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1), "algorithmic_bytes_per_launch": alg / max(launches, 1)},
+            "iterations": its}
 
 
 def main():
@@ -410,8 +479,11 @@ def main():
                     traffic_from = f"profiles/pmc_traffic.json ({pj.get('command', 'separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}); not measured in this run"
                 except Exception:
                     traffic = None
+            avg_ms = sweep_ms / max(launches, 1)
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_from": traffic_from,
+                               # north star: "achieved HBM GB/s" -- the counters' bytes per launch over THIS run's average launch time
+                               "hbm_gbs_counter": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                                "kernel": "k_sweep", "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
                                "algorithmic_bytes_per_launch": alg / max(launches, 1),
                                "index_ms": index_ms, "commit_ms": commit_ms, "sweep_ms": sweep_ms,
@@ -459,12 +531,21 @@ def main():
             out["host_transfers"] = dict(host_ms, patches_per_job=patches / max(args.steps, 1) * SCHEDULE_ITERS,
                                          pcie_inclusive_value=(patches / max(args.steps, 1) * SCHEDULE_ITERS) / (per_job + host_s), unit="patches/s",
                                          note="one job = set_views (host RGB in, pyramids on the device) + upload_patches + 3 iterations + download of the pool")
+        if world == 1 and args.config4 and not args.filter and args.views == 12 and args.width == 1920:
+            # BASELINE configs[3] in the driver's own line: the 12-view engine goes first (its memory is the card's), then the 48 x 4K run
+            e.close()
+            e = None
+            try:
+                out["config4"] = run_config4(log)
+            except Exception as err:  # the headline must not be lost to the extra block
+                out["config4"] = {"error": f"{type(err).__name__}: {err}"}
         if world == 1 and args.cpu_seconds > 0:
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(args, sc, seeds, pool_after_iter0, patches_by_iter if patches_by_iter[0] else [1, 0, 0])
             out["cpu_baseline_all_cores"] = out["cpu_baseline"]["all_cores"]
         print(json.dumps(out), file=real_stdout, flush=True)
-    e.close()
+    if e is not None:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -97,33 +97,19 @@ DEV int is_neighbor_radius(const DParams& prm, const PGeo& l, const PGeo& r, flo
     return ftmp < thr ? 1 : 0;
 }
 
-// List of (kind, view, cell): kind 0 = m_pgrids, 1 = m_vpgrids.  Snapshot lists are contiguous streams (alive entries only) -- fat
-// CellEntry records, or in the slim index the ids alone, the geometry then coming from the pool record; the destination cell being
-// processed is read through its live id list instead.
-struct ListRef { const CellEntry* fat; const int32_t* ids; int n; bool live; };
+// List of (kind, view, cell): kind 0 = m_pgrids, 1 = m_vpgrids.  Snapshot lists are contiguous runs of ids (alive entries only), the
+// geometry of an entry coming from its pool record; the destination cell being processed is read through its live id list instead.
+struct ListRef { const int32_t* ids; int n; bool live; };
 DEV ListRef cell_span(const DParams& prm, const CheckCtx& cx, int kind, int view, int cell) {
-    if (kind == 0 && view == cx.live_view && cell == cx.live_cell) return {nullptr, nullptr, cx.live_n, true};
+    if (kind == 0 && view == cx.live_view && cell == cx.live_cell) return {nullptr, cx.live_n, true};
     const int g = (prm.views + view)->cell_base + cell;
-#if MVS_FAT_INDEX
-    if (kind == 0) { const csr_off_t b = prm.csr_start[g]; return {prm.csr_fat + b, prm.csr_id32 + b, prm.csr_cnt[g], false}; }
-    const csr_off_t b = prm.vcsr_start[g];
-    return {prm.vcsr_fat + b, prm.vcsr_id32 + b, prm.vcsr_cnt[g], false};
-#else
-    if (kind == 0) { const csr_off_t b = prm.csr_start[g]; return {nullptr, prm.csr_id32 + b, prm.csr_cnt[g], false}; }
-    const csr_off_t b = prm.vcsr_start[g];
-    return {nullptr, prm.vcsr_id32 + b, prm.vcsr_cnt[g], false};
-#endif
+    if (kind == 0) return {prm.csr_id32 + prm.csr_start[g], prm.csr_cnt[g], false};
+    return {prm.vcsr_id32 + prm.vcsr_start[g], prm.vcsr_cnt[g], false};
 }
 DEV PGeo entry_geo(const DParams& prm, const CheckCtx& cx, const ListRef& l, int j, int& id) {
     if (l.live) { id = cx.live_ids[j]; return load_geo(patch_ptr(prm, cx, id)); }
-#if MVS_FAT_INDEX
-    const CellEntry e = l.fat[j];
-    id = e.id;
-    return {{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
-#else
     id = l.ids[j];
     return load_geo(prm.pool + id);  // a snapshot list names pool patches only
-#endif
 }
 
 // Filter::computeGain, filter.cpp:108-146.  One lane per (view, list entry) pair -- a list holds at most

@@ -299,14 +299,16 @@ struct Frame {
     int ok;              // 1 = the view passed the angle gate and getTexSafe
     unsigned img_lo, img_hi;  // RGBA8 pyramid level base address
 };
+// levelDiff = clamp(floor(log2(ratio) + .5)) (optim.cpp:808) as comparisons against 2^(k - .5), k = -3 .. 2 ("level
+// pick").  Those six thresholds are ONE float mantissa (that of sqrt 2, 0x3504F3) under six exponents, so for ratio = 2^e * 1.m the
+// largest k with ratio >= 2^(k - .5) is e + (m >= 0x3504F3): adding 0x800000 - 0x3504F3 to the bits carries into the exponent exactly
+// then -- three integer instructions for six compares and selects; the clamp to [-4, 2] takes care of zero, tiny and huge ratios as
+// the chain of comparisons did (a NaN ratio, which only a degenerate frame that is rejected anyway can produce, read -4 there and
+// reads 2 here).
 DEV int level_diff(const DParams& prm, float ratio) {
-    int ld = -4;
-    if (ratio >= 0.088388347648318f) ld = -3;
-    if (ratio >= 0.176776695296637f) ld = -2;
-    if (ratio >= 0.353553390593274f) ld = -1;
-    if (ratio >= 0.707106781186548f) ld = 0;
-    if (ratio >= 1.414213562373095f) ld = 1;
-    if (ratio >= 2.828427124746190f) ld = 2;
+    static_assert(0x3504F3 == (0x3FB504F3 & 0x7FFFFF), "mantissa of 1.414213562373095f");
+    const int k = ((__float_as_int(ratio) + (0x800000 - 0x3504F3)) >> 23) - 127;
+    const int ld = max(-4, min(2, k));
     return max(-prm.level, min(2, ld));
 }
 DEV float pow2_level(int ld) { return __int_as_float((127 + ld) << 23); }  // Optim::myPow2, exact powers of two
@@ -334,13 +336,14 @@ DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, b
     dx = scl3(dx, iscale);
     dy = scl3(dy, iscale);
     // Optim::getTexSafe, optim.cpp:895-915
+    // The four corners are (c -+ a) -+ b with a = dx * m, b = dy * m (each product rounded once, each sum rounded): all four sign
+    // combinations.  Rounding is monotone, so the smallest of the four is (c - |a|) - |b| and the largest (c + |a|) + |b| -- the very
+    // values the reference's min / max over the corners pick (optim.cpp:902-912), without forming the other three corners.
     const float m = (float)(prm.wsize / 2);
-    const float tlx = (center.x - dx.x * m) - dy.x * m, trx = (center.x + dx.x * m) - dy.x * m;
-    const float blx = (center.x - dx.x * m) + dy.x * m, brx = (center.x + dx.x * m) + dy.x * m;
-    const float tly = (center.y - dx.y * m) - dy.y * m, try_ = (center.y + dx.y * m) - dy.y * m;
-    const float bly = (center.y - dx.y * m) + dy.y * m, bry = (center.y + dx.y * m) + dy.y * m;
-    const float minx = fminf(tlx, fminf(trx, fminf(blx, brx))), maxx = fmaxf(tlx, fmaxf(trx, fmaxf(blx, brx)));
-    const float miny = fminf(tly, fminf(try_, fminf(bly, bry))), maxy = fmaxf(tly, fmaxf(try_, fmaxf(bly, bry)));
+    const float ax = dx.x * m, bx = dy.x * m, ay = dx.y * m, by = dy.y * m;
+    const float tlx = (center.x - ax) - bx, tly = (center.y - ay) - by;
+    const float minx = (center.x - fabsf(ax)) - fabsf(bx), maxx = (center.x + fabsf(ax)) + fabsf(bx);
+    const float miny = (center.y - fabsf(ay)) - fabsf(by), maxy = (center.y + fabsf(ay)) + fabsf(by);
     const int margin2 = 2;
     const int W = W0 >> newLevel, H = H0 >> newLevel;  // the pyramid halves (rounding down) at every level
     const bool inside = !(minx < margin2 || W - 1 - margin2 <= maxx || miny < margin2 || H - 1 - margin2 <= maxy);
@@ -1428,9 +1431,11 @@ DEV int is_visible(const DParams& prm, const Cand& c, int image, int ix, int iy,
     const F4 qc = ld4(q->coord);
     const F4 ray = nrm4(sub4(c.coord, ld4(vw->center)));
     const float diff = dot4(ray, sub4(c.coord, qc));
-    const double factor = fmin(2.0, 2.0 + (double)dot4(ray, c.normal));
+    // patch_manager.cpp:366-369: the factor is a float there (the double minimum narrowed; 2 + dot is exact in double, so this float sum is
+    // the same value), and the product and the comparison run in float
+    const float factor = fminf(2.0f, 2.0f + dot4(ray, c.normal));
     const float lhs = get_unit(prm, vw, c.coord) * (float)prm.csize * strict;
-    return (double)diff < (double)lhs * factor ? 1 : 0;
+    return diff < lhs * factor ? 1 : 0;
 }
 // PatchManager::setVImagesVGrids, patch_manager.cpp:267-301
 DEV void set_vimages_vgrids(const DParams& prm, const WaveCtx& wc, int* scratch, Cand& c) {

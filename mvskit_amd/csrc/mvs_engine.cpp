@@ -155,11 +155,10 @@ struct mvs_engine {
     bool ncc_dirty = false;
     // index
     DevBuf<int32_t> cnt, cursor, vcnt, vcursor;
-    DevBuf<csr_off_t> start, vstart;       // list offsets: 32-bit in the fat index, 64-bit in the slim one (mvs_types.h)
+    DevBuf<csr_off_t> start, vstart;       // list offsets (64-bit)
     DevBuf<int64_t> scan_tmp;              // block sums of the scans (used as int32 or as csr_off_t)
     DevBuf<unsigned long long> ids;        // the (descending ncc, id) sort keys of an index build: transient, one buffer serves both grids
-    DevBuf<CellEntry> fat, vfat;           // MVS_FAT_INDEX: the 48-byte entries
-    DevBuf<ListKey> key;                   // slim index: (m_ncc, reference view) per m_pgrids entry
+    DevBuf<ListKey> key;                   // (m_ncc, reference view) per m_pgrids entry
     DevBuf<int32_t> id32, vid32;           // the ids alone
     DevBuf<int32_t> uf_parent, uf_size;  // Filter::filterSmallGroups union-find
     DevBuf<int32_t> group_edges;         // its literal labelling: (root, root) pairs of the one-way edges between sets
@@ -302,8 +301,8 @@ DParams current_params(mvs_engine* e) {
     p.pool = e->pool.p;
     p.pool_n = e->pool_n;
     p.total_cells = e->total_cells;
-    p.csr_start = e->start.p; p.csr_cnt = e->cnt_alive.p; p.csr_fat = e->fat.p; p.csr_key = e->key.p; p.csr_id32 = e->id32.p;
-    p.vcsr_start = e->vstart.p; p.vcsr_cnt = e->vcnt_alive.p; p.vcsr_fat = e->vfat.p; p.vcsr_id32 = e->vid32.p;
+    p.csr_start = e->start.p; p.csr_cnt = e->cnt_alive.p; p.csr_key = e->key.p; p.csr_id32 = e->id32.p;
+    p.vcsr_start = e->vstart.p; p.vcsr_cnt = e->vcnt_alive.p; p.vcsr_id32 = e->vid32.p;
     p.dpgrid = e->dpgrid.p;
     return p;
 }
@@ -311,7 +310,7 @@ DParams current_params(mvs_engine* e) {
 bool want_vgrid(const mvs_engine* e) { return e->prm.depth >= 2 && e->prm.enable_check; }
 
 // One cell index (m_pgrids or m_vpgrids): count -> scan -> fill -> per-cell sort (ncc desc, id asc) [-> trim to
-// MAX_NUM_OF_PATCHES] -> compaction to alive entries, written out as fat CellEntry streams.
+// MAX_NUM_OF_PATCHES] -> compaction to alive entries, written out as id (and ListKey) streams.
 // `unordered` (the rebuilds inside Filter::run, never with the trim): the entries of a list in no particular order, see k_index_fill_direct
 int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
     hipStream_t st = e->stream;
@@ -321,7 +320,6 @@ int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
     DevBuf<csr_off_t>& start = vgrid ? e->vstart : e->start;
     DevBuf<int32_t>& cursor = vgrid ? e->vcursor : e->cursor;
     DevBuf<unsigned long long>& ids = e->ids;
-    DevBuf<CellEntry>& fat = vgrid ? e->vfat : e->fat;
     DevBuf<int32_t>& id32 = vgrid ? e->vid32 : e->id32;
     DevBuf<int32_t>& cnt_alive = vgrid ? e->vcnt_alive : e->cnt_alive;
     HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
@@ -331,32 +329,21 @@ int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
     unsigned long long tot64 = 0;
     HIPCHK(hipMemcpyAsync(&tot64, e->misc.p + 6, sizeof tot64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-#if MVS_FAT_INDEX
-    if (tot64 > (unsigned long long)(INT32_MAX - 64)) {  // every patch sits in the cell list of each of its views: this build's offsets are 32-bit
-        g_err = "cell index: more than 2^31 list entries (patches x views per patch) -- the build with the slim index (-DMVS_FAT_INDEX=0; "
-                "libmvskit_engine_cap64.so has it) takes them";
-        return MVS_ERR_CAPACITY;
-    }
-#endif
     const int64_t tot = (int64_t)tot64;
     if (!unordered) { if (int r = ids.ensure(tot + 16)) return r; }
-#if MVS_FAT_INDEX
-    if (int r = fat.ensure(tot + 16)) return r;
-#else
     if (!vgrid && !unordered) { if (int r = e->key.ensure(tot + 16)) return r; }
-#endif
     if (int r = id32.ensure(tot + 16)) return r;
     p = current_params(e);
     HIPCHK(hipMemsetAsync(cursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
     if (unordered && !trim) {
-        mvsk_index_fill_direct(p, vgrid ? 1 : 0, start.p, cursor.p, fat.p, id32.p, st);
+        mvsk_index_fill_direct(p, vgrid ? 1 : 0, start.p, cursor.p, id32.p, st);
         HIPCHK(hipMemcpyAsync(cnt_alive.p, cnt.p, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         e->lists_dense[vgrid ? 1 : 0] = true;
         return MVS_OK;
     }
     mvsk_index_fill(p, vgrid ? 1 : 0, start.p, cursor.p, ids.p, st);
     mvsk_index_sort_trim(p, start.p, ids.p, trim ? 1 : 0, e->misc.p + 3, st);
-    mvsk_index_finalize(p, vgrid ? 1 : 0, start.p, ids.p, fat.p, e->key.p, id32.p, cnt_alive.p, st);
+    mvsk_index_finalize(p, vgrid ? 1 : 0, start.p, ids.p, e->key.p, id32.p, cnt_alive.p, st);
     e->lists_dense[vgrid ? 1 : 0] = !trim;
     return MVS_OK;
 }
@@ -718,7 +705,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
     e->uf_parent.release(); e->uf_size.release(); e->group_edges.release(); e->dirty.release();
-    e->vcursor.release(); e->key.release(); e->fat.release(); e->vfat.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
+    e->vcursor.release(); e->key.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
     e->big_tables.release(); e->retry_jobs.release();
@@ -807,7 +794,7 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
             if (fit < pool_cap) pool_cap = std::max<int64_t>(fit, std::min<int64_t>(pool_cap, nc / 4 + 1024));
         }
     }
-    e->ids.headroom = e->fat.headroom = e->vfat.headroom = e->key.headroom = e->id32.headroom = e->vid32.headroom = true;
+    e->ids.headroom = e->key.headroom = e->id32.headroom = e->vid32.headroom = true;
     if (e->pool.ensure(pool_cap) || e->pool_alt.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;
     HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)pool_cap, st));
     // jobs of one colour pass over every view (upper bound, used to size the staging bookkeeping)
@@ -911,12 +898,7 @@ int mvs_engine_reserve(mvs_engine* e, int64_t list_entries) {
     if (!e || !e->have_views || list_entries < 0) { g_err = "mvs_engine_reserve: views not set, or a negative size"; return MVS_ERR_ARG; }
     HIPCHK(hipSetDevice(e->cfg.device));
     int64_t n = list_entries > 0 ? list_entries : e->total_cells * (int64_t)(e->cfg.max_propag * e->cfg.csize * e->cfg.csize);
-#if MVS_FAT_INDEX
-    n = std::min<int64_t>(n, (int64_t)INT32_MAX - 64);
-    if (e->ids.ensure(n + 16) || e->fat.ensure(n + 16) || e->vfat.ensure(n + 16) || e->id32.ensure(n + 16) || e->vid32.ensure(n + 16)) return MVS_ERR_HIP;
-#else
     if (e->ids.ensure(n + 16) || e->key.ensure(n + 16) || e->id32.ensure(n + 16) || e->vid32.ensure(n + 16)) return MVS_ERR_HIP;
-#endif
     return MVS_OK;
 }
 

@@ -107,31 +107,19 @@ __device__ __forceinline__ unsigned long long list_key(float ncc, int64_t id) {
 }
 // m_pgrids entry `pos` (an offset into the index): the fields the sweep reads of its own and its source cells
 DEV int pgrid_id(const DParams& prm, csr_off_t pos) {
-#if MVS_FAT_INDEX
-    return prm.csr_fat[pos].id;
-#else
     return prm.csr_id32[pos];
-#endif
 }
 DEV float pgrid_ncc(const DParams& prm, csr_off_t pos) {
-#if MVS_FAT_INDEX
-    return prm.csr_fat[pos].ncc;
-#else
     return prm.csr_key[pos].ncc;
-#endif
 }
 DEV int pgrid_ref(const DParams& prm, csr_off_t pos) {
-#if MVS_FAT_INDEX
-    return prm.csr_fat[pos].ref;
-#else
     return prm.csr_key[pos].ref;
-#endif
 }
 // =================================================================== index build
 // cnt[gcell] += 1 for every (patch, view) membership: PatchManager::addPatch, patch_manager.cpp:158-186
 __global__ void k_index_count(DParams prm, int32_t* __restrict__ cnt, int32_t* __restrict__ vcnt, unsigned long long* __restrict__ total) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int mine = 0;  // list entries this patch adds: their sum must stay below 2^31 (the index offsets are 32-bit)
+    int mine = 0;  // list entries this patch adds (their sum sizes the id / key buffers)
     if (id < prm.pool_n && (prm.pool[id].flags & 1)) {
         const DPatch* p = prm.pool + id;
         const F4 coord = ld4(p->coord);
@@ -181,22 +169,13 @@ __global__ void k_index_fill(DParams prm, int vgrid, const csr_off_t* __restrict
 // The index between the stages of Filter::run: no trim, and no stage depends on the order inside a list (computeGain takes maxima,
 // findNeighbors builds a set whose layout is the same for every insertion order, filterSmallGroups joins sets), so the thread that
 // holds the record writes the finished entry straight into its slot: no keys, no per-cell sort, no gather of the records.
-// (Slim index: the entry is the id; no reader inside Filter::run looks at csr_key.)
-__global__ void k_index_fill_direct(DParams prm, int vgrid, const csr_off_t* __restrict__ start, int32_t* __restrict__ cursor, CellEntry* __restrict__ fat,
-                                    int32_t* __restrict__ id32) {
+// (The entry is the id; no reader inside Filter::run looks at csr_key.)
+__global__ void k_index_fill_direct(DParams prm, int vgrid, const csr_off_t* __restrict__ start, int32_t* __restrict__ cursor, int32_t* __restrict__ id32) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= prm.pool_n) return;
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
     const F4 coord = ld4(p->coord);
-#if MVS_FAT_INDEX
-    const F4 normal = ld4(p->normal);
-    CellEntry ce;
-    ce.id = (int32_t)id; ce.ncc = p->ncc;
-    ce.coord[0] = coord.x; ce.coord[1] = coord.y; ce.coord[2] = coord.z;
-    ce.normal[0] = normal.x; ce.normal[1] = normal.y; ce.normal[2] = normal.z;
-    ce.dscale = p->dscale; ce.ref = p->images[0]; ce.pad[0] = 0; ce.pad[1] = 0;
-#endif
     const int n = vgrid ? min(p->nvimages, MVS_LISTCAP) : min(p->nimages, MVS_LISTCAP);
     for (int i = 0; i < n; ++i) {
         const DView* vw = prm.views + (vgrid ? p->vimages[i] : p->images[i]);
@@ -205,9 +184,6 @@ __global__ void k_index_fill_direct(DParams prm, int vgrid, const csr_off_t* __r
         if (ix < 0 || vw->gw <= ix || iy < 0 || vw->gh <= iy) continue;
         const int g = vw->cell_base + iy * vw->gw + ix;
         const csr_off_t slot = start[g] + atomicAdd(&cursor[g], 1);
-#if MVS_FAT_INDEX
-        fat[slot] = ce;
-#endif
         id32[slot] = (int32_t)id;
     }
 }
@@ -240,8 +216,8 @@ __global__ void k_index_sort_trim(DParams prm, const csr_off_t* __restrict__ sta
         if ((threadIdx.x & 63) == 0 && mine) atomicAdd(trimmed, (unsigned long long)mine);
     }
 }
-// After the trim: every list is compacted to its alive entries (order kept) and written out -- "fat", or as (id, ListKey).
-__global__ void k_index_finalize(DParams prm, int vgrid, const csr_off_t* __restrict__ start, const unsigned long long* __restrict__ ids, CellEntry* __restrict__ fat,
+// After the trim: every list is compacted to its alive entries (order kept) and written out as ids, m_pgrids also as ListKeys.
+__global__ void k_index_finalize(DParams prm, int vgrid, const csr_off_t* __restrict__ start, const unsigned long long* __restrict__ ids,
                                  ListKey* __restrict__ key, int32_t* __restrict__ id32, int32_t* __restrict__ cnt_alive) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= prm.total_cells) return;
@@ -251,16 +227,7 @@ __global__ void k_index_finalize(DParams prm, int vgrid, const csr_off_t* __rest
         const int id = (int)(uint32_t)ids[k];
         const DPatch* p = prm.pool + id;
         if (!(p->flags & 1)) continue;
-#if MVS_FAT_INDEX
-        CellEntry ce;
-        ce.id = id; ce.ncc = p->ncc;
-        ce.coord[0] = p->coord[0]; ce.coord[1] = p->coord[1]; ce.coord[2] = p->coord[2];
-        ce.normal[0] = p->normal[0]; ce.normal[1] = p->normal[1]; ce.normal[2] = p->normal[2];
-        ce.dscale = p->dscale; ce.ref = p->images[0]; ce.pad[0] = 0; ce.pad[1] = 0;
-        fat[b + n] = ce;
-#else
         if (!vgrid) { ListKey lk; lk.ncc = p->ncc; lk.ref = p->images[0]; key[b + n] = lk; }  // m_vpgrids' readers want ids only
-#endif
         id32[b + n] = id;
         ++n;
     }
@@ -860,14 +827,14 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
         for (int k = 0; k < 5; ++k) qc[k] = ld4((prm.pool + (dp[k] == ~0ull ? 0u : (uint32_t)(dp[k] & 0xffffffffull)))->coord);
         // PatchManager::isVisible, patch_manager.cpp:335-376: everything but the depth difference is the same for the five
         const F4 ray = nrm4(sub4(coord, ctr));
-        const double factor = fmin(2.0, 2.0 + (double)dot4(ray, normal));
+        const float factor = fminf(2.0f, 2.0f + dot4(ray, normal));  // a float in the reference (patch_manager.cpp:366), see is_visible
         float unit = 1.0f;  // get_unit
         if (ips != 0.0f) unit = (2.0f * norm4(sub4(coord, ctr)) * (float)(1 << prm.level)) / ips;
-        const double rhs = (double)(unit * (float)prm.csize * prm.neighborThreshold1) * factor;
+        const float rhs = (unit * (float)prm.csize * prm.neighborThreshold1) * factor;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const float diff = dot4(ray, sub4(coord, qc[k]));
-            const bool vis = prm.depth == 0 || dp[k] == ~0ull || (double)diff < rhs;
+            const bool vis = prm.depth == 0 || dp[k] == ~0ull || diff < rhs;
             safe |= ok[k] && vis;
         }
     }
@@ -1041,32 +1008,24 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
     int myroot = -1;
     // entry k of the 18 lists laid end to end: the list it falls in is the last lane whose list begins at or before k (lanes 18.. hold the
     // total; an empty list never wins)
-    auto entry_at = [&](int k, CellEntry& e) -> bool {
+    auto entry_at = [&](int k, int& eid) -> bool {
         int lo = 0;
 #pragma unroll
         for (int step = 16; step >= 1; step >>= 1) { const int pc = __shfl(before, lo + step); if (pc <= k) lo += step; }
         const int l_first = __shfl(before, lo);
         const csr_off_t l_start = __shfl(lstart, lo);
         if (k >= total) return false;
-#if MVS_FAT_INDEX
-        e = (lo >= 9 ? prm.vcsr_fat : prm.csr_fat)[l_start + (k - l_first)];
-#else
-        e.id = (lo >= 9 ? prm.vcsr_id32 : prm.csr_id32)[l_start + (k - l_first)];  // the slim index lists ids; edge() fetches the rest from the record
-#endif
+        eid = (lo >= 9 ? prm.vcsr_id32 : prm.csr_id32)[l_start + (k - l_first)];  // the lists hold ids; edge() fetches the geometry from the record
         return true;
     };
-    auto edge = [&](const CellEntry& e) {
-        if (e.id == (int)id) return;
+    auto edge = [&](const int eid) {
+        if (eid == (int)id) return;
         // two patches that hang on the same node are in one set already: one load instead of the predicate and the two root searches
         // of a union -- the common case once the large component has formed and its paths are short
-        if (MODE != 2 && __atomic_load_n(&parent[e.id], __ATOMIC_RELAXED) == __atomic_load_n(&parent[id], __ATOMIC_RELAXED)) return;
-#if MVS_FAT_INDEX
-        const PGeo q{{e.coord[0], e.coord[1], e.coord[2], 1.0f}, {e.normal[0], e.normal[1], e.normal[2], 0.0f}, e.dscale, e.ncc, e.ref};
-#else
-        const PGeo q = load_geo(prm.pool + e.id);  // only for the entries the same-set test lets through
-#endif
+        if (MODE != 2 && __atomic_load_n(&parent[eid], __ATOMIC_RELAXED) == __atomic_load_n(&parent[id], __ATOMIC_RELAXED)) return;
+        const PGeo q = load_geo(prm.pool + eid);  // only for the entries the same-set test lets through
         if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) return;
-        if (MODE == 0) uf_union(parent, (int)id, e.id);
+        if (MODE == 0) uf_union(parent, (int)id, eid);
         else if (MODE == 1) {
             if (!((listed >> q.ref) & 1ull)) return;
             const DView* qw = prm.views + q.ref;
@@ -1074,10 +1033,10 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
             cell_of(prm, qw, me.coord, px, py);
             cell_of(prm, qw, q.coord, qx, qy);
             if (px < 0 || qw->gw <= px || py < 0 || qw->gh <= py) return;
-            if (abs(px - qx) <= 1 && abs(py - qy) <= 1) uf_union(parent, (int)id, e.id);
+            if (abs(px - qx) <= 1 && abs(py - qy) <= 1) uf_union(parent, (int)id, eid);
         } else {
             if (myroot < 0) myroot = uf_find(parent, (int)id);
-            const int rq = uf_find(parent, e.id);
+            const int rq = uf_find(parent, eid);
             if (rq != myroot) {
                 const int k2 = atomicAdd(nedges, 1);
                 if (k2 < cap) edges[k2] = make_int2(myroot, rq);
@@ -1085,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
         }
     };
     for (int k0 = 0; k0 < total; k0 += 128) {  // two rounds of entries in flight (a patch meets ~120)
-        CellEntry e0, e1;
+        int e0 = -1, e1 = -1;
         const bool h0 = entry_at(k0 + lane, e0), h1 = entry_at(k0 + 64 + lane, e1);
         if (h0) edge(e0);
         if (h1) edge(e1);
@@ -1184,7 +1143,7 @@ void mvsk_mask_down(const uint8_t* src, int pw, int ph, uint8_t* dst, int w, int
 }
 void mvsk_mask_binarise(uint8_t* m, int64_t n, hipStream_t st) { hipLaunchKernelGGL(k_mask_binarise, dim3(nblk(n, 256)), dim3(256), 0, st, m, n); }
 void mvsk_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, hipStream_t st) { launch_exclusive_scan<int32_t, int32_t>(in, out, n, tmp, st); }
-// the per-cell counts -> list offsets (32-bit in the fat index, 64-bit in the slim one); tmp as above, in elements of csr_off_t
+// the per-cell counts -> 64-bit list offsets; tmp as above, in elements of csr_off_t
 void mvsk_exclusive_scan_off(const int32_t* in, csr_off_t* out, int64_t n, csr_off_t* tmp, hipStream_t st) { launch_exclusive_scan<int32_t, csr_off_t>(in, out, n, tmp, st); }
 void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, unsigned long long* total, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, cnt, vcnt, total);
@@ -1192,14 +1151,14 @@ void mvsk_index_count(const DParams& prm, int32_t* cnt, int32_t* vcnt, unsigned 
 void mvsk_index_fill(const DParams& prm, int vgrid, const csr_off_t* start, int32_t* cursor, unsigned long long* ids, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, vgrid, start, cursor, ids);
 }
-void mvsk_index_fill_direct(const DParams& prm, int vgrid, const csr_off_t* start, int32_t* cursor, CellEntry* fat, int32_t* id32, hipStream_t st) {
-    if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill_direct, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, vgrid, start, cursor, fat, id32);
+void mvsk_index_fill_direct(const DParams& prm, int vgrid, const csr_off_t* start, int32_t* cursor, int32_t* id32, hipStream_t st) {
+    if (prm.pool_n > 0) hipLaunchKernelGGL(k_index_fill_direct, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, vgrid, start, cursor, id32);
 }
 void mvsk_index_sort_trim(const DParams& prm, const csr_off_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
     hipLaunchKernelGGL(k_index_sort_trim, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, do_trim, trimmed);
 }
-void mvsk_index_finalize(const DParams& prm, int vgrid, const csr_off_t* start, const unsigned long long* ids, CellEntry* fat, ListKey* key, int32_t* id32, int32_t* cnt_alive, hipStream_t st) {
-    hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, vgrid, start, ids, fat, key, id32, cnt_alive);
+void mvsk_index_finalize(const DParams& prm, int vgrid, const csr_off_t* start, const unsigned long long* ids, ListKey* key, int32_t* id32, int32_t* cnt_alive, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, vgrid, start, ids, key, id32, cnt_alive);
 }
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, const uint32_t* dirty, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_depth_maps, dim3(nblk(prm.pool_n, 64)), dim3(256), 0, st, prm, dp, dirty);

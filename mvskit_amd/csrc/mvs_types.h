@@ -30,33 +30,14 @@ struct DPatch {
 static_assert(sizeof(DPatch) == 64 + 2 * MVS_MAXI, "record is 128 bytes (192 in the 64-view build)");
 #define MVS_REC_U4 (sizeof(DPatch) / 16)  // a record as 16-byte words
 
-// The cell index (PatchManager::m_pgrids / m_vpgrids as lists, patch_manager.hpp:90-104) comes in two forms, chosen at build time:
-//   MVS_FAT_INDEX 1 (the 16- and 32-view builds): per membership a 48-byte CellEntry -- the patch id plus the fields the list
-//     consumers need (sort key, reference view, the geometry of PmMvps::isNeighbor*) -- so that walking a list is one contiguous
-//     stream instead of a dependent load into the pool per entry, the ids alone again as a compact int32 array, 32-bit offsets:
-//     60 bytes per membership with the sort keys, patches x views per patch < 2^31;
-//   MVS_FAT_INDEX 0 (the 64-view build; any build with -DMVS_FAT_INDEX=0): per membership the 4-byte id, for m_pgrids also an 8-byte
-//     ListKey (m_ncc and the reference view: what the sweep reads of its own and its source cells), 64-bit offsets; the geometry of a
-//     listed patch comes from its pool record (one cache line).  12 bytes per membership with the transient sort keys (one buffer
-//     serves both grids), no 2^31 limit: what a 48-view data set needs, whose patches sit in 20-40 lists each.
-#ifndef MVS_FAT_INDEX
-#define MVS_FAT_INDEX (MVS_LISTCAP <= 32)
-#endif
-#if MVS_FAT_INDEX
-typedef int32_t csr_off_t;
-#else
+// The cell index (PatchManager::m_pgrids / m_vpgrids as lists, patch_manager.hpp:90-104), rebuilt from the pool before every pass:
+// per membership -- a patch sits in the list of one cell in each of its views -- the 4-byte patch id, for m_pgrids also an 8-byte
+// ListKey (m_ncc and the reference view: what the sweep reads of its own and its source cells), 64-bit offsets per cell.  The geometry
+// of a listed patch comes from its pool record (one cache line).  With the transient sort keys of a build (one buffer serves both
+// grids) that is 12 bytes per membership and no 2^31 limit on patches x views per patch -- rounds 1-3 kept a 48-byte entry with the
+// geometry per membership behind 32-bit offsets (60 bytes, 55 M patches at 48 views); measured on the 16-view build the id lists
+// are as fast in the sweep and faster in Filter::run's rebuilds.
 typedef int64_t csr_off_t;
-#endif
-struct CellEntry {
-    int32_t id;
-    float ncc;
-    float coord[3];
-    float normal[3];
-    float dscale;
-    int32_t ref;
-    int32_t pad[2];
-};
-static_assert(sizeof(CellEntry) == 48, "cell entry is 48 bytes");
 struct ListKey {
     float ncc;
     int32_t ref;
@@ -99,12 +80,10 @@ struct DParams {
     // (ncc desc, id asc) in Propagate::run
     const csr_off_t* csr_start;
     const int32_t* csr_cnt;
-    const CellEntry* csr_fat;  // MVS_FAT_INDEX only
-    const ListKey* csr_key;    // !MVS_FAT_INDEX only: (m_ncc, reference view), parallel to csr_id32; valid after a Propagate::run index build
-    const int32_t* csr_id32;   // the ids alone: findNeighbors' first phase walks ids only (4 B per patch met)
+    const ListKey* csr_key;    // (m_ncc, reference view), parallel to csr_id32; valid after a Propagate::run index build
+    const int32_t* csr_id32;   // the ids: findNeighbors' first phase walks nothing else (4 B per patch met)
     const csr_off_t* vcsr_start;
     const int32_t* vcsr_cnt;
-    const CellEntry* vcsr_fat; // MVS_FAT_INDEX only
     const int32_t* vcsr_id32;
     const unsigned long long* dpgrid;  // (sortable depth << 32 | id), ~0ull = m_MAXDEPTH
 };

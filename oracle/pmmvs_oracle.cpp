@@ -1079,8 +1079,10 @@ int is_visible(const Scene& s, const Patch& p, int image, int ix, int iy, float 
     V4 ray = sub4(p.coord, vw.center);
     ray = nrm4(ray);
     const float diff = dot4(ray, sub4(p.coord, dpp.coord));
-    const double factor = std::min(2.0, 2.0 + dot4(ray, p.normal));
-    return diff < get_unit(s, image, p.coord) * s.cfg.csize * strict * factor ? 1 : 0;
+    /* patch_manager.cpp:366: `const float factor = std::min(2.0, 2.0 + ray.dot(normal))` -- the double minimum is narrowed to float, and
+     * the product and the comparison of :369 run in float (2 + dot is exact in double, so the narrowing equals the float sum) */
+    const float factor = (float)std::min(2.0, 2.0 + (double)dot4(ray, p.normal));
+    return diff < get_unit(s, image, p.coord) * (float)s.cfg.csize * strict * factor ? 1 : 0;
 }
 
 /* PatchManager::setVImagesVGrids, patch_manager.cpp:267-301 */

@@ -228,10 +228,10 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
     (pmmvps.cpp:90-110) -- Propagate::run, Filter::run, updateThreshold, ++m_depth -- so Optim::check runs from the second
     iteration on and Filter::run five times at that size.  Too large for the oracle: the engine is held to the properties that do
     not depend on the size, and what it took (HBM, time per stage) is recorded in gpurun_out/config4_run.json.
-    Seeds: one per 4x4 cells in the central half x half of every view's grid (1.5 M seeds, a quarter of the cells): every patch sits
-    in the cell lists of ~36 of the 48 views, the index offsets are 32-bit (patches x views per patch < 2^31: at most ~55 M patches
-    at this list length; `mvs_engine_pass` reports MVS_ERR_CAPACITY beyond) and an index entry takes 60 bytes, so a pool grown over
-    ALL 99.5 M cells does not fit one card's index -- the seeded quarter does, at the same addressing, list lengths and kernels."""
+    Seeds: one per 4x4 cells over ALL cells of ALL 48 grids (6.2 M seeds).  Every patch sits in the cell lists of 20-40 views; the
+    index holds a 4-byte id per membership (an 8-byte key more for m_pgrids) behind 64-bit offsets, so the billions of memberships of
+    this pool fit the card (rounds 1-3 seeded the central quarter only: a 60-byte entry behind 32-bit offsets capped the pool at
+    ~55 M patches)."""
     import json
     import os
     import time
@@ -242,10 +242,11 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
     n = sc.nviews
     seeds = synth.make_seeds(sc, level=0, csize=2, stride=4, seed=777)
     cx, cy = _cells_in_ref_view(sc, seeds)
-    seeds = np.ascontiguousarray(seeds[(cx >= 480) & (cx < 1440) & (cy >= 270) & (cy < 810)])
-    assert seeds.shape[0] > 1_000_000 and len(set(seeds["images"][:, 0].tolist())) == n
+    assert seeds.shape[0] > 5_000_000 and len(set(seeds["images"][:, 0].tolist())) == n
+    assert cx.min() < 64 and cx.max() > 1855 and cy.min() < 64 and cy.max() > 1015  # no mask: the seeds reach the borders of the grids
+    MAX_PATCHES = 128_000_000
     free0, total_mem = torch.cuda.mem_get_info(0)
-    e = engine.Engine(n, max_patches=60_000_000, **CFG)
+    e = engine.Engine(n, max_patches=MAX_PATCHES, **CFG)
     assert e.list_cap == 64 and e.dtype.itemsize == 192  # more than 32 views: libmvskit_engine_cap64.so
     e.set_scene(sc)
     assert e.grid_dims(47) == (1920, 1080)
@@ -265,15 +266,16 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
         peak = max(peak, (free0 - free1) / 2 ** 30)
         assert c["candidates"] == c["prefiltered"] + c["patches"], (it, c)
         assert c["patches"] == c["fail0"] + c["fail1"] + c["inserted"] + c["replaced"], (it, c)
-        assert c["patches"] > 1_000_000 and c["inserted"] > 500_000, (it, c)
+        assert c["patches"] > 4_000_000 and c["inserted"] > 2_000_000, (it, c)
         assert all(v >= 0 for v in f.values())
         log.append({"iteration": it, "counters": c, "propagate_s": t1 - t0, "timing_ms": t, "filter_removed": f, "filter_s": t2 - t1,
                     "filter_total_ms": fs["total_ms"], "pool_alive": e.num_patches(), "hbm_used_GiB": (free0 - free1) / 2 ** 30})
     assert log[1]["counters"]["fail1"] > 0 or log[2]["counters"]["fail1"] > 0  # Optim::check (m_depth >= 2) rejects something at this size too
     assert sum(sum(l["filter_removed"].values()) for l in log) > 0
     p = e.patches()
-    made = p[p["dscale"] > 0]
-    assert made.shape[0] > 5_000_000
+    assert p.shape[0] > 20_000_000  # the central-quarter runs of round 3 ended with 9.2 M
+    made = p[p["dscale"] > 0][::5]  # the properties below on every fifth patch (host time)
+    assert made.shape[0] > 3_000_000
     assert made["nimages"].min() >= CFG["minImageNum"] and made["nimages"].max() > 32  # lists longer than the 32-view build could keep
     k = np.arange(64)[None, :] < made["nimages"][:, None]
     imgs = np.where(k, made["images"], 255)
@@ -295,7 +297,7 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
     np.testing.assert_allclose(depth[have], d, rtol=1e-5)
     assert peak < 288.0
     rec = {"views": n, "width": sc.W, "height": sc.H, "list_cap": e.list_cap, "record_bytes": int(e.dtype.itemsize), "cells": 48 * 1920 * 1080, "seeds": int(seeds.shape[0]),
-           "max_patches": 60_000_000, "iterations": log, "hbm_peak_GiB": peak, "hbm_total_GiB": total_mem / 2 ** 30, "pool_alive": int(p.shape[0]),
+           "max_patches": MAX_PATCHES, "seeding": "1 seed per 4x4 cells over all cells of all 48 grids", "iterations": log, "hbm_peak_GiB": peak, "hbm_total_GiB": total_mem / 2 ** 30, "pool_alive": int(p.shape[0]),
            "mean_nimages": float(made["nimages"].mean()), "max_nimages": int(made["nimages"].max())}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)

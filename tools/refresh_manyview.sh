@@ -6,7 +6,7 @@ R=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-config5 --cpu-seconds 0"
+B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-config5 --no-config4 --cpu-seconds 0"
 M="--views 48 --width 960 --height 540"
 timeout -k 10 300 $B $M --list-cap 32 > $out/${R}_bench_48x540p_cap32.json 2> $out/${R}_bench_48x540p_cap32.log
 timeout -k 10 300 $B $M > $out/${R}_bench_48x540p.json 2> $out/${R}_bench_48x540p.log

@@ -7,7 +7,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B0="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1"
-B="$B0 --no-config5"
+B="$B0 --no-config5 --no-config4"
 echo "== bench (with CPU baseline and the config5 block)"; timeout -k 10 500 $B0 > $out/${R}_bench_1gpu.json 2> $out/${R}_bench_1gpu.log
 echo "== kernel trace"; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $B --cpu-seconds 0 > $out/kt.log 2>&1
 echo "== pmc fetch"; timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- $B --cpu-seconds 0 > $out/fetch.log 2>&1
