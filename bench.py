@@ -359,6 +359,13 @@ def main():
             reset_state()
         step(s % SCHEDULE_ITERS)
 
+    def pool_digest(recs):
+        import hashlib
+
+        b = recs[["coord", "normal", "ncc", "dscale", "nimages", "nvimages", "images", "vimages"]].tobytes() if recs.shape[0] else b""
+        return int.from_bytes(hashlib.blake2b(b, digest_size=7).digest(), "little") ^ (int(recs.shape[0]) << 1)
+
+    pool_hashes = []
     patches = view_evals = evals = 0
     sweep_ms = index_ms = commit_ms = exchange_ms = 0.0
     launches = exchange_bytes = local_view_evals = 0
@@ -388,6 +395,11 @@ def main():
             fstats[k] = fstats.get(k, 0) + v
         if it == 0 and pool_after_iter0 is None and world == 1 and args.cpu_seconds > 0 and not args.filter:
             pool_after_iter0 = e.patches()  # for the CPU baseline's sample B (untimed: after the closing barrier)
+        if world > 1 and it == SCHEDULE_ITERS - 1:
+            # self-validation of a multi-rank run (untimed): every rank hashes the pool it holds at the end of a repetition; the hashes
+            # are all-gathered below.  The result does not depend on the sharding, so all ranks must hold the SAME pool -- and `patches`
+            # of the whole job must equal the one-GPU run's for the same --steps.
+            pool_hashes.append(pool_digest(e.patches()))
     dt = timed
     if world > 1:
         tt = torch.tensor([dt, float(patches), float(view_evals)], dtype=torch.float64, device="cpu" if shared_gpu else device)
@@ -396,6 +408,18 @@ def main():
         sm = tt.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt = float(mx[0]); patches = int(sm[1]); view_evals = int(sm[2])
+    validation = None
+    if world > 1:
+        info = e.comm_info() if ex is not None else {"world": 0, "comm_count": -1}
+        mine = torch.tensor((pool_hashes + [0] * 64)[:64] + [len(pool_hashes), info["world"], info["comm_count"]], dtype=torch.int64, device="cpu" if shared_gpu else device)
+        allh = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        allh = [t.cpu().tolist() for t in allh]
+        nrep = allh[0][64]
+        validation = {"ranks_identical": bool(nrep > 0 and all(a[:65] == allh[0][:65] for a in allh)), "repetitions_hashed": int(nrep),
+                      "rccl_world": [int(a[66]) for a in allh], "engine_world": [int(a[65]) for a in allh],
+                      "note": "every rank hashes its pool (coordinates, normals, scores, lists) after each repetition; identical hashes on all ranks = identical pools; "
+                              "rccl_world = ncclCommCount of each rank's communicator (-1: the transport cannot be asked, 0 where the host-staged rehearsal uses none)"}
     # BASELINE configs[4] ("12-view 1080p with filter.cpp geometric-consistency pass fused on GPU") beside the headline: one more
     # repetition of the 3-iteration schedule with Filter::run (filter.cpp:25-49) after every iteration, as PmMvps::run has it
     # (pmmvps.cpp:95-105), on its own clock -- the headline `value` above is not touched by it.
@@ -490,6 +514,10 @@ def main():
                                "index_ms_per_step": index_ms / max(args.steps, 1), "commit_ms_per_step": commit_ms / max(args.steps, 1),
                                "note": "achieved = 588 B x view evaluations counted on the device / HIP-event time of k_sweep; the label is the contract's choice of "
                                        "two: the kernel is bound by VALU issue (DESIGN.md section 5) and the 131 MB of pyramids sit in the Infinity Cache"}
+            if validation is not None:
+                out["validation"] = validation
+                out["ranks_identical"] = validation["ranks_identical"]
+                out["rccl_world"] = validation["rccl_world"][0]
             if ex is not None:
                 out["roofline"]["rank"] = 0
                 out["exchange"] = {"ms": exchange_ms, "bytes_gathered_per_rank": exchange_bytes, "collective": exchange}

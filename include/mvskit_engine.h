@@ -218,6 +218,17 @@ int mvs_engine_comm_init(mvs_engine* e, const void* id /* MVS_COMM_ID_BYTES */, 
 int mvs_engine_comm_attach(mvs_engine* e, void* nccl_comm /* ncclComm_t the host owns */, int rank, int world);
 int mvs_engine_comm_release(mvs_engine* e); /* destroys the communicator comm_init made / forgets an attached one */
 int mvs_engine_exchange(mvs_engine* e);     /* after mvs_engine_pass: all-gather + commit of the union; collective */
+/* rank / world the engine was given (world 0: no communicator) and what the communicator itself reports (ncclCommCount,
+ * ncclCommUserRank; -1 where the collective library does not export them) -- for a launcher that wants to see that N ranks really
+ * share one communicator (bench.py --gpus N prints it as `rccl_world`) */
+int mvs_engine_comm_info(mvs_engine* e, int* rank, int* world, int* comm_count, int* comm_rank);
+/* FAILURES in a multi-rank job.  A failure on one rank (its pass overflowed, an allocation did not fit, a HIP error) reaches every
+ * rank: mvs_engine_exchange's first all-gather and the agreement in front of every collective of mvs_engine_filter carry a status
+ * word, all ranks give the call up together and return the same status; nobody waits.  Two things cannot be agreed on: no device
+ * memory for the status word itself, and a failure of the collective library -- the rank returns MVS_ERR_HIP alone and the job
+ * must be torn down by its launcher (torch.distributed.run and bench.py --gpus N both end the job when a rank exits non-zero).
+ * After an error from mvs_engine_filter the stages that completed stand on every rank alike; the stage that was under way may
+ * have rewritten lists of this rank's share only: re-upload the patches or stop. */
 
 /* parity artefact: kind 0 = m_dpgrids patch, kind 1 = best-NCC patch of
  * m_pgrids[view][cell] whose reference view is `view`.  depth[gw*gh] = oaxis.coord, normal[gw*gh*3],

@@ -72,10 +72,10 @@ DEV int is_neighbor_h(const DParams& prm, const PGeo& l, const PGeo& r, float hu
     const float vunit = l.dscale + r.dscale;
     const float f0 = dot4(l.normal, diff), f1 = dot4(r.normal, diff);
     float ftmp = (fabsf(f0) + fabsf(f1)) / 2.0f;
-    ftmp /= vunit;
+    ftmp = div_rn(ftmp, vunit);  // two seeds without a depth scale (vunit 0): infinity or NaN either way, and neither is < thr
     const F4 h = add4(sub4(diff, mul4(l.normal, f0)), sub4(diff, mul4(r.normal, f1)));
-    const float hsize = norm4(h) / 2.0f / hunit;
-    if (1.0f < hsize) ftmp /= fminf(2.0f, hsize);
+    const float hsize = div_rn(norm4(h) / 2.0f, hunit);
+    if (1.0f < hsize) ftmp = div_rn(ftmp, fminf(2.0f, hsize));
     return ftmp < thr ? 1 : 0;
 }
 DEV int is_neighbor(const DParams& prm, const PGeo& l, const PGeo& r, float thr) {
@@ -89,11 +89,11 @@ DEV int is_neighbor_radius(const DParams& prm, const PGeo& l, const PGeo& r, flo
     const float vunit = l.dscale + r.dscale;
     const float f0 = dot4(l.normal, diff), f1 = dot4(r.normal, diff);
     float ftmp = (fabsf(f0) + fabsf(f1)) / 2.0f;
-    ftmp /= vunit;
+    ftmp = div_rn(ftmp, vunit);
     const F4 h = sub4(sub4(mul4(diff, 2.0f), mul4(l.normal, f0)), mul4(r.normal, f1));
-    const float hsize = norm4(h) / 2.0f / hunit;
-    if (radius / hunit < hsize) return 0;
-    if (1.0f < hsize) ftmp /= fminf(2.0f, hsize);
+    const float hsize = div_rn(norm4(h) / 2.0f, hunit);
+    if (div_rn(radius, hunit) < hsize) return 0;
+    if (1.0f < hsize) ftmp = div_rn(ftmp, fminf(2.0f, hsize));
     return ftmp < thr ? 1 : 0;
 }
 
@@ -221,7 +221,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
         u = get_unit(prm, vw, c.coord);
         const F4 ray = nrm4(sub4(ld4(vw->center), c.coord));
         const float d = dot4(ray, c.normal);
-        if (0.0f < d) u /= d; else u = (float)(INT_MAX / 2);
+        if (0.0f < d) u = div_rn(u, d); else u = (float)(INT_MAX / 2);
     }
     const float m1 = wave_min(u);
     const unsigned long long eq = ballot(wc.lane < c.nimg && u == m1);
@@ -234,7 +234,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
         float gu = 0.0f;
         if (wc.lane < c.nimg) gu = get_unit(prm, prm.views + c.img, c.coord);
         for (int i = 0; i < c.nimg; ++i) unit += rlf(gu, i);
-        unit /= (float)c.nimg;
+        unit = div_rn(unit, (float)c.nimg);
         unit *= (float)prm.csize;
     }
     const float thr = prm.neighborThreshold * scale;
@@ -407,7 +407,7 @@ DEV void ortho(F4 z, F4& x, F4& y) {
     else if (fabsf(z.y) > 0.5f) x = {0.0f, z.z, -z.y, 0.0f};
     else x = {-z.z, 0.0f, z.x, 0.0f};
     const float n = norm4(x);
-    x = {x.x / n, x.y / n, x.z / n, x.w / n};
+    x = {div_rn(x.x, n), div_rn(x.y, n), div_rn(x.z, n), div_rn(x.w, n)};
     y = {z.y * x.z - z.z * x.y, z.z * x.x - z.x * x.z, z.x * x.y - z.y * x.x, 0.0f};
 }
 
@@ -502,13 +502,13 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
         tb_stf<G>(rows, 3 * t + 0, dot4(diff, xdir)); tb_stf<G>(rows, 3 * t + 1, dot4(diff, ydir)); tb_stf<G>(rows, 3 * t + 2, dot4(diff, c.normal));
     }
     float h = wave_sum(hp);
-    h /= (float)n;
+    h = div_rn(h, (float)n);
     // Filter::lls: M = [A^T A | A^T b] with A = (fx^2, fy^2, fx fy, fx, fy), b = fz; 15 + 5 distinct sums, in double
     double acc[20];
 #pragma unroll
     for (int k = 0; k < 20; ++k) acc[k] = 0.0;
     for (int t = wc.lane; t < n; t += 64) {  // each lane reads back what it wrote
-        const float fx = tb_ldf<G>(rows, 3 * t + 0) / h, fy = tb_ldf<G>(rows, 3 * t + 1) / h, fz = tb_ldf<G>(rows, 3 * t + 2);
+        const float fx = div_rn(tb_ldf<G>(rows, 3 * t + 0), h), fy = div_rn(tb_ldf<G>(rows, 3 * t + 1), h), fz = tb_ldf<G>(rows, 3 * t + 2);
         tb_stf<G>(rows, 3 * t + 0, fx); tb_stf<G>(rows, 3 * t + 1, fy);
         const float a[6] = {fx * fx, fy * fy, fx * fy, fx, fy, fz};
         int k = 0;
@@ -592,16 +592,16 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
         float gu = 0.0f;
         if (wc.lane < inum) gu = get_unit(prm, prm.views + c.img, c.coord);
         for (int i = 0; i < inum; ++i) unit += rlf(gu, i);
-        unit /= (float)inum;
+        unit = div_rn(unit, (float)inum);
     }
     float rp = 0.0f;
     for (int t = wc.lane; t < n; t += 64) {
         const float fx = tb_ldf<G>(rows, 3 * t), fy = tb_ldf<G>(rows, 3 * t + 1), fz = tb_ldf<G>(rows, 3 * t + 2);
         const float res = x0 * (fx * fx) + x1 * (fy * fy) + x2 * (fx * fy) + x3 * fx + x4 * fy - fz;
-        rp += fabsf(res) / unit;
+        rp += div_rn(fabsf(res), unit);
     }
     float residual = wave_sum(rp);
-    residual /= (float)(n - 5);
+    residual = div_rn(residual, (float)(n - 5));
     return residual < prm.quadThreshold ? 0 : 1;
 }
 

@@ -75,6 +75,31 @@ DEV float sqrt_rn(float x) {
     s = ru > 0.0f ? up : s;
     return s;
 }
+// Correctly rounded reciprocal and quotient in 3 and 6 instructions where the compiler's IEEE expansion takes 11 (v_div_scale x 2,
+// v_rcp, four fma, v_div_fmas, v_div_fixup): v_rcp_f32 is within one ulp, one Newton step in fma lands on RN(1 / x); the quotient is
+// Markstein's q' = RN(q + (a - b q) y) with y = RN(1 / b).  tools/microbench/div_exact.hip runs rcp_rn against `1.0f / x` for EVERY
+// float with 2^-120 <= |x| < 2^121 (4.04 * 10^9 inputs: no difference) and div_rn against `a / b` on 1.18 * 10^10 pairs (none) --
+// profiles/r04_div_exact.txt.  Outside that range (zero, subnormal, infinite or NaN divisors, quotients that over- or underflow) they
+// differ from IEEE division; they are used only where the divisor is a length, a depth, a focal scale or 1 + 3 incc of this path.
+#ifndef MVS_FASTDIV
+#define MVS_FASTDIV 1
+#endif
+DEV float rcp_rn(float x) {
+#if MVS_FASTDIV
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+#else
+    return 1.0f / x;
+#endif
+}
+DEV float div_rn(float a, float b) {
+#if MVS_FASTDIV
+    const float y = rcp_rn(b), q = a * y;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
+#else
+    return a / b;
+#endif
+}
 DEV float norm4(F4 a) { return sqrt_rn(dot4(a, a)); }
 DEV float norm3(F3 a) { return sqrt_rn(dot3(a, a)); }
 DEV F4 sub4(F4 a, F4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
@@ -82,8 +107,8 @@ DEV F4 add4(F4 a, F4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 DEV F4 mul4(F4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
 DEV F3 sub3(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 // v / |v| as v * (1/|v|) (Eigen 3.2 vector / scalar semantics; one IEEE division instead of three or four)
-DEV F4 nrm4(F4 a) { const float inv = 1.0f / norm4(a); return {a.x * inv, a.y * inv, a.z * inv, a.w * inv}; }
-DEV F3 nrm3(F3 a) { const float inv = 1.0f / norm3(a); return {a.x * inv, a.y * inv, a.z * inv}; }
+DEV F4 nrm4(F4 a) { const float inv = rcp_rn(norm4(a)); return {a.x * inv, a.y * inv, a.z * inv, a.w * inv}; }
+DEV F3 nrm3(F3 a) { const float inv = rcp_rn(norm3(a)); return {a.x * inv, a.y * inv, a.z * inv}; }
 DEV F4 scl4(F4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
 DEV F3 scl3(F3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 DEV F3 cross3(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
@@ -220,7 +245,7 @@ DEV F3 project(const DView* vw, F4 X, int level) {
     float r2 = fma_(P[11], X.w, fma_(P[10], X.z, fma_(P[9], X.y, P[8] * X.x)));
     if (r2 <= 0.0f) return {-65535.0f, -65535.0f, -1.0f};
     const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
-    const float inv = 1.0f / r2;
+    const float inv = rcp_rn(r2);
     F3 ic{r0 * inv, r1 * inv, 1.0f};
     ic.x = fmaxf(lo, fminf(hi, ic.x));
     ic.y = fmaxf(lo, fminf(hi, ic.y));
@@ -232,7 +257,7 @@ DEV F3 project_regs(const float (&P)[12], F4 X) {
     const float r1 = fma_(P[7], X.w, fma_(P[6], X.z, fma_(P[5], X.y, P[4] * X.x)));
     const float r2 = fma_(P[11], X.w, fma_(P[10], X.z, fma_(P[9], X.y, P[8] * X.x)));
     const float lo = (float)(INT_MIN + 3.0f), hi = (float)(INT_MAX - 3.0f);
-    const float inv = 1.0f / r2;
+    const float inv = rcp_rn(r2);  // r2 <= 0 is replaced below whatever this gave
     F3 ic{fmaxf(lo, fminf(hi, r0 * inv)), fmaxf(lo, fminf(hi, r1 * inv)), 1.0f};
     if (r2 <= 0.0f) ic = {-65535.0f, -65535.0f, -1.0f};
     return ic;
@@ -254,7 +279,7 @@ DEV float get_unit(const DParams& prm, const DView* vw, F4 coord) {
     const float fz = norm4(sub4(coord, ld4(vw->center)));
     const float ips = vw->ipscale;
     if (ips == 0.0f) return 1.0f;
-    return (2.0f * fz * (float)(1 << prm.level)) / ips;
+    return div_rn(2.0f * fz * (float)(1 << prm.level), ips);
 }
 // PatchManager::setGrids cell rule, patch_manager.cpp:241-250
 DEV void cell_of(const DParams& prm, const DView* vw, F4 coord, int& ix, int& iy) {
@@ -264,7 +289,17 @@ DEV void cell_of(const DParams& prm, const DView* vw, F4 coord, int& ix, int& iy
     ix = ((int)floorf(ic.x + 0.5f)) / prm.csize;
     iy = ((int)floorf(ic.y + 0.5f)) / prm.csize;
 }
-// Optim::getPAxes, optim.cpp:67-84 (the view's constants are loaded once, up front)
+// Optim::getPAxes, optim.cpp:67-84 (the view's constants are loaded once, up front).
+// Every caller hands in a patch that is the same in all 16 lanes of a row (one patch per wave in the single evaluations, a proposal per
+// row in the refinement steps, a patch per 16 / 32 / 64 lanes in Filter::filterExact).  The three projections of the reference view --
+// of the patch's centre and of the centre moved along either axis -- are independent, so lanes 0, 1, 2 of every row take one each
+// (the other lanes repeat the centre's), the two distances and their reciprocals come out of ONE norm / division sequence in lanes 1
+// and 2, and the row reads them back with row broadcasts (DPP row_newbcast, no LDS): one projection, one square root and one division
+// per step where each lane used to run three, two and two.  The point a lane projects is coord + a px + b py with (a, b) = (0, 0),
+// (1, 0) or (0, 1): fma(b, py, fma(a, px, coord)) is coord, RN(coord + px) or RN(coord + py) exactly -- the reference's coord + pxaxis.
+template <int LANE> DEV float row_bcast_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + LANE, 0xf, 0xf, false));  // row_newbcast:LANE
+}
 DEV void get_paxes(const DParams& prm, const DView* vw, F4 coord, F4 normal, F4& px, F4& py) {
     const F4 ctr = ld4(vw->center);
     const float ips = vw->ipscale;
@@ -272,21 +307,35 @@ DEV void get_paxes(const DParams& prm, const DView* vw, F4 coord, F4 normal, F4&
     float P[12];
     load_P(vw, prm.level, P);
     float pscale = 1.0f;  // get_unit
-    if (ips != 0.0f) pscale = (2.0f * norm4(sub4(coord, ctr)) * (float)(1 << prm.level)) / ips;
+    if (ips != 0.0f) pscale = div_rn(2.0f * norm4(sub4(coord, ctr)) * (float)(1 << prm.level), ips);
     F3 n3{normal.x, normal.y, normal.z};
     F3 y3 = cross3(n3, xax);
     y3 = nrm3(y3);
     F3 x3 = cross3(y3, n3);
     px = {x3.x * pscale, x3.y * pscale, x3.z * pscale, 0.0f};
     py = {y3.x * pscale, y3.y * pscale, y3.z * pscale, 0.0f};
+#ifndef MVS_PAXES_SPREAD
+#define MVS_PAXES_SPREAD 1
+#endif
+#if MVS_PAXES_SPREAD
+    const int j = lane_id() & 15;
+    const float a = j == 1 ? 1.0f : 0.0f, b = j == 2 ? 1.0f : 0.0f;
+    const F4 X{fma_(b, py.x, fma_(a, px.x, coord.x)), fma_(b, py.y, fma_(a, px.y, coord.y)), fma_(b, py.z, fma_(a, px.z, coord.z)), coord.w};
+    const F3 ic = project_regs(P, X);
+    const F3 c0{row_bcast_f<0>(ic.x), row_bcast_f<0>(ic.y), row_bcast_f<0>(ic.z)};
+    const float inv = rcp_rn(norm3(sub3(ic, c0)));  // lane 1: 1 / xdis, lane 2: 1 / ydis (lane 0 and the rest: 1 / 0, never read)
+    px = scl4(px, row_bcast_f<1>(inv));
+    py = scl4(py, row_bcast_f<2>(inv));
+#else
     const F3 c0 = project_regs(P, coord);
     const float xdis = norm3(sub3(project_regs(P, add4(coord, px)), c0));
     const float ydis = norm3(sub3(project_regs(P, add4(coord, py)), c0));
-    px = scl4(px, 1.0f / xdis);
-    py = scl4(py, 1.0f / ydis);
+    px = scl4(px, rcp_rn(xdis));
+    py = scl4(py, rcp_rn(ydis));
+#endif
 }
-DEV float robustincc(float incc) { return incc / (1 + 3 * incc); }
-DEV float unrobustincc(float r) { return r / (1 - 3 * r); }
+DEV float robustincc(float incc) { return div_rn(incc, 1 + 3 * incc); }
+DEV float unrobustincc(float r) { return div_rn(r, 1 - 3 * r); }
 
 // ------------------------------------------------------------------ texture frames (frame lanes)
 // Head of Optim::getTex, optim.cpp:790-818: per (proposal, view) the sampling frame (top-left, dx, dy), the
@@ -305,11 +354,25 @@ struct Frame {
 // then -- three integer instructions for six compares and selects; the clamp to [-4, 2] takes care of zero, tiny and huge ratios as
 // the chain of comparisons did (a NaN ratio, which only a degenerate frame that is rejected anyway can produce, read -4 there and
 // reads 2 here).
+#ifndef MVS_FS1
+#define MVS_FS1 1
+#endif
 DEV int level_diff(const DParams& prm, float ratio) {
+#if MVS_FS1
     static_assert(0x3504F3 == (0x3FB504F3 & 0x7FFFFF), "mantissa of 1.414213562373095f");
     const int k = ((__float_as_int(ratio) + (0x800000 - 0x3504F3)) >> 23) - 127;
     const int ld = max(-4, min(2, k));
     return max(-prm.level, min(2, ld));
+#else
+    int ld = -4;
+    if (ratio >= 0.088388347648318f) ld = -3;
+    if (ratio >= 0.176776695296637f) ld = -2;
+    if (ratio >= 0.353553390593274f) ld = -1;
+    if (ratio >= 0.707106781186548f) ld = 0;
+    if (ratio >= 1.414213562373095f) ld = 1;
+    if (ratio >= 2.828427124746190f) ld = 2;
+    return max(-prm.level, min(2, ld));
+#endif
 }
 DEV float pow2_level(int ld) { return __int_as_float((127 + ld) << 23); }  // Optim::myPow2, exact powers of two
 // Straight-line: every load of the view's constants is issued at the top (one wait instead of one per early exit --
@@ -340,10 +403,19 @@ DEV Frame make_frame(const DParams& prm, F4 coord, F4 px, F4 py, F4 pz, int v, b
     // combinations.  Rounding is monotone, so the smallest of the four is (c - |a|) - |b| and the largest (c + |a|) + |b| -- the very
     // values the reference's min / max over the corners pick (optim.cpp:902-912), without forming the other three corners.
     const float m = (float)(prm.wsize / 2);
+#if MVS_FS1
     const float ax = dx.x * m, bx = dy.x * m, ay = dx.y * m, by = dy.y * m;
     const float tlx = (center.x - ax) - bx, tly = (center.y - ay) - by;
     const float minx = (center.x - fabsf(ax)) - fabsf(bx), maxx = (center.x + fabsf(ax)) + fabsf(bx);
     const float miny = (center.y - fabsf(ay)) - fabsf(by), maxy = (center.y + fabsf(ay)) + fabsf(by);
+#else
+    const float tlx = (center.x - dx.x * m) - dy.x * m, trx = (center.x + dx.x * m) - dy.x * m;
+    const float blx = (center.x - dx.x * m) + dy.x * m, brx = (center.x + dx.x * m) + dy.x * m;
+    const float tly = (center.y - dx.y * m) - dy.y * m, try_ = (center.y + dx.y * m) - dy.y * m;
+    const float bly = (center.y - dx.y * m) + dy.y * m, bry = (center.y + dx.y * m) + dy.y * m;
+    const float minx = fminf(tlx, fminf(trx, fminf(blx, brx))), maxx = fmaxf(tlx, fmaxf(trx, fmaxf(blx, brx)));
+    const float miny = fminf(tly, fminf(try_, fminf(bly, bry))), maxy = fmaxf(tly, fmaxf(try_, fmaxf(bly, bry)));
+#endif
     const int margin2 = 2;
     const int W = W0 >> newLevel, H = H0 >> newLevel;  // the pyramid halves (rounding down) at every level
     const bool inside = !(minx < margin2 || W - 1 - margin2 <= maxx || miny < margin2 || H - 1 - margin2 <= maxy);
@@ -406,7 +478,7 @@ DEV void frames_publish(const WaveCtx& wc, const Frame& f, int nlanes) {
 DEV float inv_msd(const DParams& prm, float ssd) {
     float msd = sqrt_rn(ssd * prm.inv_3sz);
     if (msd == 0.0f) msd = 1.0f;
-    return 1.0f / msd;
+    return rcp_rn(msd);
 }
 
 // ------------------------------------------------------------------ class-lane evaluation (the four proposals of a refinement step)
@@ -884,14 +956,14 @@ DEV float compute_weights(const DParams& prm, const WaveCtx& wc, F4 coord, F4 no
         const float ips = vw->ipscale;
         const F4 dc = sub4(coord, ctr);
         float u = 1.0f;  // get_unit
-        if (ips != 0.0f) u = (2.0f * norm4(dc) * (float)(1 << prm.level)) / ips;
+        if (ips != 0.0f) u = div_rn(2.0f * norm4(dc) * (float)(1 << prm.level), ips);
         const F4 ray = nrm4(sub4(ctr, coord));
         const float d = dot4(ray, normal);
-        u = (0.0f < d) ? u / d : (float)(INT_MAX / 2);
+        u = (0.0f < d) ? div_rn(u, d) : (float)(INT_MAX / 2);
         if (wc.lane < n) unit = u;
     }
     const float w0 = rlf(unit, 0);
-    float w = fminf(1.0f, w0 / unit);
+    float w = fminf(1.0f, div_rn(w0, unit));
     if (wc.lane == 0) w = 1.0f;
     return w;
 }
@@ -918,7 +990,7 @@ DEV float compute_incc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int
         score += rlf(val_l, i) * w;
     }
     if (total == 0.0f) return 2.0f;
-    return score / total;
+    return div_rn(score, total);
 }
 // tail of Optim::computeINCC (optim.cpp:690-705) on per-view robust INCCs that are already known
 DEV float weighted_incc(const DParams& prm, vmask_t okm, float val_l, float weights, int n) {
@@ -932,7 +1004,7 @@ DEV float weighted_incc(const DParams& prm, vmask_t okm, float val_l, float weig
         score += rlf(val_l, i) * w;
     }
     if (total == 0.0f) return 2.0f;
-    return score / total;
+    return div_rn(score, total);
 }
 // PatchManager::computeNcc, patch_manager.cpp:401-404
 DEV float compute_ncc(const DParams& prm, WaveCtx& wc, F4 coord, F4 normal, int img, int n) {
@@ -1037,10 +1109,10 @@ DEV void sort_images(const DParams& prm, const WaveCtx& wc, Cand& c) {
         const F4 r = nrm4(sub4(ctr, c.coord));
         const float d = dot4(r, c.normal);
         float u = 1.0f;  // get_unit
-        if (ips != 0.0f) u = (2.0f * norm4(sub4(c.coord, ctr)) * (float)(1 << prm.level)) / ips;
+        if (ips != 0.0f) u = div_rn(2.0f * norm4(sub4(c.coord, ctr)) * (float)(1 << prm.level), ips);
         valid = in && !(d <= 0.0f);
         if (in) ray = r;
-        if (valid) unit = u / d;
+        if (valid) unit = div_rn(u, d);
     }
     const unsigned long long vm = ballot(valid);
     const int n0 = __popcll(vm);
@@ -1061,7 +1133,7 @@ DEV void sort_images(const DParams& prm, const WaveCtx& wc, Cand& c) {
         active &= ~(1ull << sel);
         if (act && wc.lane != sel) {
             const float ftmp = fminf(thr, fmaxf(thr / 2.0f, 1.0f - dot4(rsel, ray)));
-            unit = unit * thr / ftmp;
+            unit = div_rn(unit * thr, ftmp);
         }
         ++k;
     }
@@ -1087,7 +1159,7 @@ DEV void set_scales(const DParams& prm, const WaveCtx& wc, Cand& c) {
     }
     float ds = c.dscale;
     for (int i = 1; i < num; ++i) ds += rlf(dn, i);
-    ds /= (float)(num - 1);
+    ds = div_rn(ds, (float)(num - 1));
     ds = unit2 / ds;
     c.dscale = ds;
     c.ascale = pm_atanf(ds / (unit * (float)prm.wsize / 2.0f));
@@ -1344,7 +1416,7 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     // q = pair_index(a, b) goes to LDS behind the textures.
 #if !MVS_PAIR_MFMA
     const int npairs = n * (n - 1) / 2;
-    float* pairv = texs + MVS_LISTCAP * 3 * tstride;  // behind the textures
+    float* pairv = texs + prm.list_n * 3 * tstride;  // behind the textures (list_n = min(MVS_LISTCAP, nviews): no list is longer)
 #endif
 #if MVS_PAIR_MFMA
     // The evaluation left the Gram matrix of its textures at texs[a * MVS_GRAM_LD + b] (eval_views).  Row by row, lane b > a turns

@@ -69,6 +69,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;     // optional (mvs_engine_comm_info)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;  // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -95,6 +97,7 @@ Rccl& rccl() {
     MVS_SYM(GetUniqueId, "ncclGetUniqueId"); MVS_SYM(CommInitRank, "ncclCommInitRank"); MVS_SYM(CommDestroy, "ncclCommDestroy");
     MVS_SYM(AllGather, "ncclAllGather"); MVS_SYM(Broadcast, "ncclBroadcast"); MVS_SYM(GroupStart, "ncclGroupStart");
     MVS_SYM(GroupEnd, "ncclGroupEnd"); MVS_SYM(GetErrorString, "ncclGetErrorString");
+    MVS_SYM(CommCount, "ncclCommCount"); MVS_SYM(CommUserRank, "ncclCommUserRank");
 #undef MVS_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Broadcast && r.GroupStart && r.GroupEnd && r.GetErrorString;
     return r;
@@ -1197,6 +1200,20 @@ int mvs_engine_comm_release(mvs_engine* e) {
         (void)rccl().CommDestroy(e->comm);
     }
     e->comm = nullptr; e->comm_owned = false; e->comm_rank = 0; e->comm_world = 1;
+    return MVS_OK;
+}
+
+int mvs_engine_comm_info(mvs_engine* e, int* rank, int* world, int* comm_count, int* comm_rank) {
+    if (!e) return MVS_ERR_ARG;
+    if (rank) *rank = e->comm_rank;
+    if (world) *world = e->comm ? e->comm_world : 0;  // 0: no communicator attached
+    int cc = -1, cr = -1;  // what the communicator itself says (ncclCommCount / ncclCommUserRank), -1 where it cannot be asked
+    if (e->comm && rccl().ok) {
+        if (rccl().CommCount && rccl().CommCount(e->comm, &cc) != ncclSuccess) cc = -1;
+        if (rccl().CommUserRank && rccl().CommUserRank(e->comm, &cr) != ncclSuccess) cr = -1;
+    }
+    if (comm_count) *comm_count = cc;
+    if (comm_rank) *comm_rank = cr;
     return MVS_OK;
 }
 

@@ -1183,7 +1183,7 @@ size_t mvsk_sweep_lds_bytes(const DParams& prm) {
     const size_t tex_f = (size_t)MVS_GRAM_CH * 3 * prm.wsz, gram_f = (size_t)MVS_GRAM_LD * MVS_GRAM_LD;
     const size_t texs = MVS_FRAME1_LDS_BYTES + (tex_f > gram_f ? tex_f : gram_f) * sizeof(float);
 #else
-    const size_t ln = MVS_LISTCAP;
+    const size_t ln = (size_t)prm.list_n;  // min(MVS_LISTCAP, nviews): a 12-view data set keeps 12 textures, not 16
     const size_t texs = MVS_FRAME1_LDS_BYTES + (ln * 3 * prm.wsz + ln * (ln - 1) / 2) * sizeof(float);
 #endif
     const size_t chk = (size_t)MVS_CHECK_LDS_FLOATS * sizeof(float);                      // Optim::check hash set + rows
@@ -1243,8 +1243,20 @@ void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_
 void mvsk_filter_outside(const DParams& prm, uint8_t* kill, int64_t first, int64_t last, hipStream_t st) {
     if (last > first) hipLaunchKernelGGL(k_filter_outside, dim3((unsigned)(last - first)), dim3(64), 0, st, prm, kill, first);
 }
+// Filter::filterExact needs the LDS of setRefImage only (frames + the textures of a list), not Optim::check's id set: 7.9 KB instead of
+// 9.5 KB per wave at 12 views -- the kernel waits on dependent gathers (vector ALU busy 37 %), so resident waves are what it lacks
+size_t mvsk_texs_lds_bytes(const DParams& prm) {
+#if MVS_PAIR_MFMA
+    const size_t tex_f = (size_t)MVS_GRAM_CH * 3 * prm.wsz, gram_f = (size_t)MVS_GRAM_LD * MVS_GRAM_LD;
+    const size_t texs = MVS_FRAME1_LDS_BYTES + (tex_f > gram_f ? tex_f : gram_f) * sizeof(float);
+#else
+    const size_t ln = (size_t)prm.list_n;
+    const size_t texs = MVS_FRAME1_LDS_BYTES + (ln * 3 * prm.wsz + ln * (ln - 1) / 2) * sizeof(float);
+#endif
+    return texs > (size_t)MVS_FRAME_LDS_BYTES ? texs : (size_t)MVS_FRAME_LDS_BYTES;
+}
 void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, int64_t first, int64_t last, hipStream_t st) {
-    if (last > first) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)((last - first + MVS_FE_PATCHES - 1) / MVS_FE_PATCHES)), dim3(64), mvsk_sweep_lds_bytes(prm), st, prm, kill, evals, stage, first, last);
+    if (last > first) hipLaunchKernelGGL(k_filter_exact, dim3((unsigned)((last - first + MVS_FE_PATCHES - 1) / MVS_FE_PATCHES)), dim3(64), mvsk_texs_lds_bytes(prm), st, prm, kill, evals, stage, first, last);
 }
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, int64_t first, int64_t last, hipStream_t st) {
     if (last <= first) return;

@@ -23,7 +23,7 @@ EXPORTS = [
     "mvs_engine_pass", "mvs_engine_export_counts", "mvs_engine_export_device", "mvs_engine_commit_device",
     "mvs_engine_commit_local", "mvs_engine_depth_normal_map", "mvs_engine_probe", "mvs_engine_last_timing",
     "mvs_engine_filter", "mvs_comm_unique_id", "mvs_engine_comm_init", "mvs_engine_comm_attach", "mvs_engine_comm_release",
-    "mvs_engine_exchange", "mvs_list_cap", "mvs_engine_filter_stats", "mvs_patch_bytes", "mvs_engine_reserve",
+    "mvs_engine_exchange", "mvs_list_cap", "mvs_engine_filter_stats", "mvs_patch_bytes", "mvs_engine_reserve", "mvs_engine_comm_info",
 ]
 
 
@@ -287,6 +287,13 @@ class Engine:
     def comm_init(self, uid: bytes, rank: int, world: int):
         assert len(uid) == self.COMM_ID_BYTES
         self._check(self.L.mvs_engine_comm_init(self.h, C.c_char_p(uid), rank, world))
+
+    def comm_info(self):
+        """rank / world the engine holds and what its communicator reports (ncclCommCount / ncclCommUserRank; -1 if it cannot be asked)"""
+        r, w, cc, cr = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.L.mvs_engine_comm_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        self._check(self.L.mvs_engine_comm_info(self.h, C.byref(r), C.byref(w), C.byref(cc), C.byref(cr)))
+        return {"rank": r.value, "world": w.value, "comm_count": cc.value, "comm_rank": cr.value}
 
     def comm_release(self):
         self._check(self.L.mvs_engine_comm_release(self.h))

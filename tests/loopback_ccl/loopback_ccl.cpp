@@ -137,6 +137,18 @@ ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataT
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+    const Comm* c = reinterpret_cast<const Comm*>(comm);
+    if (!c || !count) return ncclInvalidArgument;
+    *count = c->world;
+    return ncclSuccess;
+}
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
+    const Comm* c = reinterpret_cast<const Comm*>(comm);
+    if (!c || !rank) return ncclInvalidArgument;
+    *rank = c->rank;
+    return ncclSuccess;
+}
 ncclResult_t ncclGroupStart() { return ncclSuccess; }
 ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 
