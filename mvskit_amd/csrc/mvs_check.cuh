@@ -210,15 +210,17 @@ DEV bool set_insert_from(int* table, unsigned mask, int k, unsigned p) {
     return false;
 }
 #define MVS_FN_INFLIGHT 4  // id loads in flight in the row walk (8, 16, 32 measured the same or slower)
-template <int HCAP, bool G = false, bool ROWS = false /* the index has no gaps (built without the trim): walk it by grid rows */>
+template <int HCAP, bool G = false>
 DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin,
                        unsigned* stats = nullptr) {
     const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
     // Propagate::computeRadius, propagate.cpp:474-481: the second smallest unit
     float u = __int_as_float(0x7f800000);
+    float gu = 0.0f;
     if (wc.lane < c.nimg) {
         const DView* vw = prm.views + c.img;
-        u = get_unit(prm, vw, c.coord);
+        gu = get_unit(prm, vw, c.coord);
+        u = gu;
         const F4 ray = nrm4(sub4(ld4(vw->center), c.coord));
         const float d = dot4(ray, c.normal);
         if (0.0f < d) u = div_rn(u, d); else u = (float)(INT_MAX / 2);
@@ -230,127 +232,96 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     const float second = c.nimg > 1 ? m2 : m1;
     const float radius = (float)(1.5 * (double)margin * (double)(second * (float)prm.csize));
     float unit = 0.0f;
-    {
-        float gu = 0.0f;
-        if (wc.lane < c.nimg) gu = get_unit(prm, prm.views + c.img, c.coord);
-        for (int i = 0; i < c.nimg; ++i) unit += rlf(gu, i);
-        unit = div_rn(unit, (float)c.nimg);
-        unit *= (float)prm.csize;
-    }
+    for (int i = 0; i < c.nimg; ++i) unit += rlf(gu, i);
+    unit = div_rn(unit, (float)c.nimg);
+    unit *= (float)prm.csize;
     const float thr = prm.neighborThreshold * scale;
     CK_BEGIN()
     __syncthreads();
     for (int t = wc.lane; t < HCAP; t += 64) tb_st<G>(table, t, MVS_SET_EMPTY);
     __syncthreads();
-    // ---- phase A
-    const int side = 2 * margin + 1, per = side * side;
-    const int ntask = c.nimg * per;
+    // ---- phase A.  Every index the engine builds is dense -- the lists of neighbouring cells lie end to end -- so the (2 margin + 1)
+    // cells of a grid row are ONE run of ids.  A lane per row (view, kind, dy) fetches its run, the runs are laid end to end and the
+    // lanes take consecutive ids (the run of an id: a binary search over the running totals, which sit in the lanes): 64 useful ids
+    // per load and per round of LDS atomics, where a lane per list ran as long as the longest list of 64.  (Filter::filterNeighbor has
+    // walked its lists this way since round 3; inside the sweep the m_pgrids index had gaps where the trim had removed entries, and a
+    // lane per (view, cell) list walked both lists of its cell: since round 4 the trimmed index is packed, k_index_pack.)
+    // The destination cell being processed is read through its LIVE list: its row is cut in two around it -- the left part stays in
+    // the row's own lane, the right part and the live list take two extra lanes behind the regular rows.
+    // The final layout does not depend on the order of the insertions.
+    const int side = 2 * margin + 1;
+    const int nimg = __builtin_amdgcn_readfirstlane(c.nimg);
+    const int nrow = 2 * side * nimg;
+    // is the live cell inside the window of its view?
+    int live_i = -1, lcx = 0, lcy = 0;
+    if (cx.live_view >= 0) {
+        const unsigned long long lm = ballot(wc.lane < nimg && c.img == cx.live_view);
+        if (lm) {
+            const int i = __ffsll((long long)lm) - 1;
+            const int gw = (prm.views + cx.live_view)->gw;
+            lcx = cx.live_cell % gw; lcy = cx.live_cell / gw;
+            const int gx = rli(c.gx, i), gy = rli(c.gy, i);
+            if (abs(lcx - gx) <= margin && abs(lcy - gy) <= margin) live_i = i;
+        }
+    }
+    const int nrow_all = nrow + (live_i >= 0 ? 2 : 0);
     bool full = false;
     unsigned n_entries = 0;
-    // the ids of a list from entry j_from on, four at a time: the first probe of the four keys together (four LDS atomics in
-    // flight): most keys are duplicates of one already in the set or find their slot empty, and are done here; the rest walk on
-    // one by one.  The final layout does not depend on the order of the insertions.
-    auto walk = [&](const ListRef& l, int j_from) {
-        for (int j0 = j_from; j0 < l.n; j0 += 4) {
-            int id[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = min(j0 + q, l.n - 1);
-                id[q] = l.live ? cx.live_ids[j] : l.ids[j];
-            }
-            unsigned slot[4];
-            int old[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                slot[q] = set_home<HCAP>(id[q]);
-                old[q] = (j0 + q < l.n) ? atomicMax(&table[slot[q]], id[q]) : id[q];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (old[q] == id[q] || old[q] == MVS_SET_EMPTY) continue;
-                const int carry = old[q] < id[q] ? old[q] : id[q];  // took the slot of a smaller key: carry that one on
-                if (!set_insert_from(table, HCAP - 1, carry, (slot[q] + 1) & (HCAP - 1))) full = true;
+    for (int r0 = 0; r0 < nrow_all; r0 += 64) {
+        const int r = r0 + wc.lane, rc = min(r, nrow - 1);
+        const bool right = live_i >= 0 && r == nrow, livel = live_i >= 0 && r == nrow + 1;
+        const int i = right ? live_i : rc / (2 * side), dy = rc % side - margin;
+        const bool vk = !right && ((rc / side) & 1) != 0;
+        const int v = __shfl(c.img, i), gx = __shfl(c.gx, i), gy = __shfl(c.gy, i);
+        csr_off_t b = 0;
+        int len = 0, src = vk ? 1 : 0;  // 0: m_pgrids ids, 1: m_vpgrids ids, 2: the live list (LDS)
+        if (livel) { len = cx.live_n; src = 2; }
+        else if (r < nrow_all) {
+            const DView* vw = prm.views + v;
+            const int yt = right ? lcy : gy + dy;
+            int x0 = max(gx - margin, 0), x1 = min(gx + margin, vw->gw - 1);
+            if (right) x0 = lcx + 1;
+            else if (live_i == i && !vk && yt == lcy) x1 = min(x1, lcx - 1);  // the live cell's row: its part left of the cell
+            if (0 <= yt && yt < vw->gh && x0 <= x1) {
+                const csr_off_t* st = vk ? prm.vcsr_start : prm.csr_start;
+                const int g0 = vw->cell_base + yt * vw->gw + x0;
+                b = st[g0];
+                len = (int)(st[g0 + (x1 - x0) + 1] - b);
             }
         }
-    };
-    if (!ROWS) {
-        for (int t0 = 0; t0 < ntask; t0 += 64) {
-            const int t = t0 + wc.lane;
-            const int i = min(t / per, c.nimg - 1), r = t % per;
-            const int v = __shfl(c.img, i), gx = __shfl(c.gx, i), gy = __shfl(c.gy, i);  // all lanes take part in the shuffles
-            if (t < ntask) {
-                const DView* vw = prm.views + v;
-                const int yt = gy + r / side - margin, xt = gx + r % side - margin;
-                if (!(yt < 0 || vw->gh <= yt || xt < 0 || vw->gw <= xt)) {
-                    const int cell = yt * vw->gw + xt;
-                    for (int kind = 0; kind < 2; ++kind) {
-                        const ListRef l = cell_span(prm, cx, kind, v, cell);
-                        n_entries += (unsigned)l.n;
-                        walk(l, 0);
-                    }
-                }
+        int P = len;  // the running total over the lanes: inclusive, then exclusive
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(P, d); if (wc.lane >= d) P += o; }
+        const int total = __builtin_amdgcn_readlane(P, 63);
+        P -= len;
+        if (wc.lane == 0) n_entries += (unsigned)total;
+        for (int k0 = 0; k0 < total; k0 += 64 * MVS_FN_INFLIGHT) {
+            int id[MVS_FN_INFLIGHT];
+#pragma unroll
+            for (int q = 0; q < MVS_FN_INFLIGHT; ++q) {
+                const int k = k0 + 64 * q + wc.lane;
+                int lo = 0;  // the run id k falls in: the last lane whose run begins at or before k
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) { const int pc = __shfl(P, lo + step); if (pc <= k) lo += step; }
+                const csr_off_t bb = __shfl(b, lo);
+                const int pl = __shfl(P, lo), sr = __shfl(src, lo);
+                int v_id = MVS_SET_EMPTY;
+                if (k < total) v_id = sr == 2 ? cx.live_ids[k - pl] : (sr == 1 ? prm.vcsr_id32 : prm.csr_id32)[bb + (k - pl)];
+                id[q] = v_id;
             }
-        }
-    } else {
-        // Filter::filterNeighbor (a wave per patch).  Its indexes are built without the trim (Filter::setDepthMapsVGridsVPGridsAddPatchV),
-        // so the lists of neighbouring cells lie end to end: the (2 margin + 1) cells of a grid row are ONE run of ids.  A lane per row
-        // (view, kind, dy) fetches its run, the runs are laid end to end and the lanes take consecutive ids (the run of an id: a binary
-        // search over the running totals, which sit in the lanes): 64 useful ids per load and per round of LDS atomics, where the
-        // lane-per-list walk above runs as long as the longest list of 64.  The kernel is bound by instruction issue (vector ALU busy
-        // 86 % of the time, profiles/r03_pmc_filter_kernels.json), so what counts is instructions per id; a row per step with its
-        // start in scalar registers needs fewer per load but twice the rounds of atomics, and measured slower (67.6 against 61.6 ms).
-        // The final layout does not depend on the order of the insertions.
-        const int nrow = 2 * side * __builtin_amdgcn_readfirstlane(c.nimg);
-        for (int r0 = 0; r0 < nrow; r0 += 64) {
-            const int r = r0 + wc.lane, rc = min(r, nrow - 1);
-            const int i = rc / (2 * side), dy = rc % side - margin;
-            const bool vk = ((rc / side) & 1) != 0;
-            const int v = __shfl(c.img, i), gx = __shfl(c.gx, i), gy = __shfl(c.gy, i);
-            csr_off_t b = 0;
-            int len = 0;
-            if (r < nrow) {
-                const DView* vw = prm.views + v;
-                const int yt = gy + dy, x0 = max(gx - margin, 0), x1 = min(gx + margin, vw->gw - 1);
-                if (0 <= yt && yt < vw->gh && x0 <= x1) {
-                    const csr_off_t* st = vk ? prm.vcsr_start : prm.csr_start;
-                    const int g0 = vw->cell_base + yt * vw->gw + x0;
-                    b = st[g0];
-                    len = (int)(st[g0 + (x1 - x0) + 1] - b);
-                }
-            }
-            int P = len;  // the running total over the lanes: inclusive, then exclusive
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(P, d); if (wc.lane >= d) P += o; }
-            const int total = __builtin_amdgcn_readlane(P, 63);
-            P -= len;
-            if (wc.lane == 0) n_entries += (unsigned)total;
-            for (int k0 = 0; k0 < total; k0 += 64 * MVS_FN_INFLIGHT) {
-                int id[MVS_FN_INFLIGHT];
 #pragma unroll
-                for (int u = 0; u < MVS_FN_INFLIGHT; ++u) {
-                    const int k = k0 + 64 * u + wc.lane;
-                    int lo = 0;  // the run id k falls in: the last lane whose run begins at or before k
+            for (int u0 = 0; u0 < MVS_FN_INFLIGHT; u0 += 4) {
+                if (k0 + 64 * u0 >= total) break;
+                unsigned slot[4];
+                int old[4];
 #pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) { const int pc = __shfl(P, lo + step); if (pc <= k) lo += step; }
-                    const csr_off_t bb = __shfl(b, lo);
-                    const int pl = __shfl(P, lo);
-                    const bool kv = (((r0 + lo) / side) & 1) != 0;
-                    id[u] = k < total ? (kv ? prm.vcsr_id32 : prm.csr_id32)[bb + (k - pl)] : MVS_SET_EMPTY;
+                for (int q = 0; q < 4; ++q) {
+                    slot[q] = set_home<HCAP>(id[u0 + q]);
+                    old[q] = id[u0 + q] != MVS_SET_EMPTY ? atomicMax(&table[slot[q]], id[u0 + q]) : id[u0 + q];
                 }
 #pragma unroll
-                for (int u0 = 0; u0 < MVS_FN_INFLIGHT; u0 += 4) {
-                    if (k0 + 64 * u0 >= total) break;
-                    unsigned slot[4];
-                    int old[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        slot[u] = set_home<HCAP>(id[u0 + u]);
-                        old[u] = id[u0 + u] != MVS_SET_EMPTY ? atomicMax(&table[slot[u]], id[u0 + u]) : id[u0 + u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (old[u] == id[u0 + u] || old[u] == MVS_SET_EMPTY) continue;
-                        if (!set_insert_from(table, HCAP - 1, old[u] < id[u0 + u] ? old[u] : id[u0 + u], (slot[u] + 1) & (HCAP - 1))) full = true;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    if (old[q] == id[u0 + q] || old[q] == MVS_SET_EMPTY) continue;
+                    if (!set_insert_from(table, HCAP - 1, old[q] < id[u0 + q] ? old[q] : id[u0 + q], (slot[q] + 1) & (HCAP - 1))) full = true;
                 }
             }
         }
@@ -396,7 +367,7 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     if (visited > HCAP - HCAP / 8) return -1;  // beyond 7/8 full the oracle's table-size rule picks the next size
     if (stats) {
         for (int d = 32; d >= 1; d >>= 1) n_entries += (unsigned)__shfl_xor((int)n_entries, d);
-        stats[0] = 2u * (unsigned)ntask; stats[1] = n_entries; stats[2] = (unsigned)visited; stats[3] = (unsigned)count;
+        stats[0] = 2u * (unsigned)(nimg * side * side); stats[1] = n_entries; stats[2] = (unsigned)visited; stats[3] = (unsigned)count;
     }
     return count;
 }

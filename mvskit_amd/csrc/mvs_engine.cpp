@@ -159,6 +159,8 @@ struct mvs_engine {
     // index
     DevBuf<int32_t> cnt, cursor, vcnt, vcursor;
     DevBuf<csr_off_t> start, vstart;       // list offsets (64-bit)
+    DevBuf<csr_off_t> start_raw;           // m_pgrids offsets of a build with the trim, before the lists are packed end to end
+    DevBuf<int32_t> id32_raw;              // ... and its ids, each list compacted to the front of its own range
     DevBuf<int64_t> scan_tmp;              // block sums of the scans (used as int32 or as csr_off_t)
     DevBuf<unsigned long long> ids;        // the (descending ncc, id) sort keys of an index build: transient, one buffer serves both grids
     DevBuf<ListKey> key;                   // (m_ncc, reference view) per m_pgrids entry
@@ -344,10 +346,17 @@ int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
         e->lists_dense[vgrid ? 1 : 0] = true;
         return MVS_OK;
     }
-    mvsk_index_fill(p, vgrid ? 1 : 0, start.p, cursor.p, ids.p, st);
-    mvsk_index_sort_trim(p, start.p, ids.p, trim ? 1 : 0, e->misc.p + 3, st);
-    mvsk_index_finalize(p, vgrid ? 1 : 0, start.p, ids.p, e->key.p, id32.p, cnt_alive.p, st);
-    e->lists_dense[vgrid ? 1 : 0] = !trim;
+    // sorted lists [and the trim]: keys -> per-cell sort -> [trim] -> each list's alive entries to the front of its range -> the lists
+    // packed end to end (a second scan, over the alive counts), so that every index the engine builds is dense
+    if (int r = e->id32_raw.ensure(tot + 16)) return r;
+    DevBuf<csr_off_t>& raw = e->start_raw;
+    HIPCHK(hipMemcpyAsync(raw.p, start.p, (size_t)(nc + 1) * sizeof(csr_off_t), hipMemcpyDeviceToDevice, st));
+    mvsk_index_fill(p, vgrid ? 1 : 0, raw.p, cursor.p, ids.p, st);
+    mvsk_index_sort_trim(p, raw.p, ids.p, trim ? 1 : 0, e->misc.p + 3, st);
+    mvsk_index_finalize(p, vgrid ? 1 : 0, raw.p, ids.p, e->id32_raw.p, cnt_alive.p, st);
+    mvsk_exclusive_scan_off(cnt_alive.p, start.p, nc, reinterpret_cast<csr_off_t*>(e->scan_tmp.p), st);
+    mvsk_index_pack(p, raw.p, start.p, cnt_alive.p, ids.p, e->id32_raw.p, vgrid ? nullptr : e->key.p, id32.p, st);
+    e->lists_dense[vgrid ? 1 : 0] = true;
     return MVS_OK;
 }
 int build_depth(mvs_engine* e) {  // m_dpgrids from the alive pool
@@ -367,7 +376,8 @@ int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
     mvsk_fill_ncc(p, e->misc.p + 1, st);
     e->ncc_dirty = false;
     if (int r = build_list(e, false, true)) return r;
-    if (want_vgrid(e)) if (int r = build_list(e, true, false)) return r;
+    // m_vpgrids: no reader depends on the order inside its lists (findNeighbors' set, filterSmallGroups' unions): written without keys and sort
+    if (want_vgrid(e)) if (int r = build_list(e, true, false, true)) return r;
     if (int r = build_depth(e)) return r;
     if (trimmed_out) {
         HIPCHK(hipMemcpyAsync(trimmed_out, e->misc.p + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -708,7 +718,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
     e->uf_parent.release(); e->uf_size.release(); e->group_edges.release(); e->dirty.release();
-    e->vcursor.release(); e->key.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
+    e->vcursor.release(); e->key.release(); e->start_raw.release(); e->id32_raw.release(); e->id32.release(); e->vid32.release(); e->cnt_alive.release(); e->vcnt_alive.release(); e->scan_tmp.release(); e->dpgrid.release(); e->best.release();
     e->staging.release(); e->job_stage.release(); e->job_nstage.release(); e->job_cnt.release(); e->job_base_scan.release();
     e->kill_cnt.release(); e->kill_base.release(); e->per_view.release(); e->misc.release(); e->counters.release(); e->error_flag.release();
     e->big_tables.release(); e->retry_jobs.release();
@@ -778,7 +788,7 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
     HIPCHK(hipMemcpyAsync(e->dviews.p, e->hviews.data(), sizeof(DView) * nviews, hipMemcpyHostToDevice, st));
     const int64_t nc = e->total_cells;
     if (e->cnt.ensure(nc + 2) || e->start.ensure(nc + 2) || e->cursor.ensure(nc + 2) || e->vcnt.ensure(nc + 2) || e->vstart.ensure(nc + 2) ||
-        e->vcursor.ensure(nc + 2) || e->dpgrid.ensure(nc + 2) || e->best.ensure(nc + 2) || e->cnt_alive.ensure(nc + 2) || e->vcnt_alive.ensure(nc + 2))
+        e->vcursor.ensure(nc + 2) || e->start_raw.ensure(nc + 2) || e->dpgrid.ensure(nc + 2) || e->best.ensure(nc + 2) || e->cnt_alive.ensure(nc + 2) || e->vcnt_alive.ensure(nc + 2))
         return MVS_ERR_HIP;
     // Pool capacity: mvs_config.max_patches, else 4 patches per cell (the 1080p runs settle near 1 per cell) -- but never
     // more than a sixth of the device's memory for each of the two pool buffers: the index, staging and scans grow with it.
@@ -797,7 +807,7 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
             if (fit < pool_cap) pool_cap = std::max<int64_t>(fit, std::min<int64_t>(pool_cap, nc / 4 + 1024));
         }
     }
-    e->ids.headroom = e->key.headroom = e->id32.headroom = e->vid32.headroom = true;
+    e->ids.headroom = e->key.headroom = e->id32.headroom = e->id32_raw.headroom = e->vid32.headroom = true;
     if (e->pool.ensure(pool_cap) || e->pool_alt.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;
     HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)pool_cap, st));
     // jobs of one colour pass over every view (upper bound, used to size the staging bookkeeping)
@@ -901,7 +911,7 @@ int mvs_engine_reserve(mvs_engine* e, int64_t list_entries) {
     if (!e || !e->have_views || list_entries < 0) { g_err = "mvs_engine_reserve: views not set, or a negative size"; return MVS_ERR_ARG; }
     HIPCHK(hipSetDevice(e->cfg.device));
     int64_t n = list_entries > 0 ? list_entries : e->total_cells * (int64_t)(e->cfg.max_propag * e->cfg.csize * e->cfg.csize);
-    if (e->ids.ensure(n + 16) || e->key.ensure(n + 16) || e->id32.ensure(n + 16) || e->vid32.ensure(n + 16)) return MVS_ERR_HIP;
+    if (e->ids.ensure(n + 16) || e->key.ensure(n + 16) || e->id32.ensure(n + 16) || e->id32_raw.ensure(n + 16) || e->vid32.ensure(n + 16)) return MVS_ERR_HIP;
     return MVS_OK;
 }
 
@@ -996,7 +1006,8 @@ static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
         if (split_mode > 0 && nj > 0) {
             const DParams p0 = current_params(e);
             int shift = 0;  // the scan is 32-bit: scale the proxy down if its worst case would not fit
-            while ((((int64_t)3 * e->prm.cap * e->prm.max_propag * 32 * nj) >> shift) >= (int64_t)INT32_MAX) ++shift;
+            // (every job's work is rounded UP after the shift, so the 32-bit prefix sum may exceed the shifted bound by up to nj)
+            while ((((int64_t)3 * e->prm.cap * e->prm.max_propag * 32 * nj) >> shift) + nj >= (int64_t)INT32_MAX) ++shift;
             mvsk_job_work(p0, a, split_mode, shift, e->job_cnt.p, st);
             mvsk_exclusive_scan(e->job_cnt.p, e->job_base_scan.p, nj, reinterpret_cast<int32_t*>(e->scan_tmp.p), st);
             if (int r = e->tmp_i.ensure(N + 1)) return r;

@@ -14,7 +14,9 @@ void mvsk_exclusive_scan_off(const int32_t* in, csr_off_t* out, int64_t n, csr_o
 void mvsk_index_fill(const DParams& prm, int vgrid, const csr_off_t* start, int32_t* cursor, unsigned long long* ids, hipStream_t st);
 void mvsk_index_fill_direct(const DParams& prm, int vgrid, const csr_off_t* start, int32_t* cursor, int32_t* id32, hipStream_t st);
 void mvsk_index_sort_trim(const DParams& prm, const csr_off_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st);
-void mvsk_index_finalize(const DParams& prm, int vgrid, const csr_off_t* start, const unsigned long long* ids, ListKey* key, int32_t* id32, int32_t* cnt_alive, hipStream_t st);
+void mvsk_index_finalize(const DParams& prm, int vgrid, const csr_off_t* start, unsigned long long* ids, int32_t* id32, int32_t* cnt_alive, hipStream_t st);
+void mvsk_index_pack(const DParams& prm, const csr_off_t* start, const csr_off_t* start2, const int32_t* cnt_alive, const unsigned long long* ids, const int32_t* id32_in,
+                     ListKey* key, int32_t* id32_out, hipStream_t st);
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, const uint32_t* dirty, hipStream_t st);
 void mvsk_depth_mark_dirty(const DParams& prm, const uint8_t* kill, unsigned long long* dp, uint32_t* dirty, hipStream_t st);
 void mvsk_best_ncc_map(const DParams& prm, int view, unsigned long long* best, hipStream_t st);

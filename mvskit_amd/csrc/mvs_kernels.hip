@@ -216,9 +216,11 @@ __global__ void k_index_sort_trim(DParams prm, const csr_off_t* __restrict__ sta
         if ((threadIdx.x & 63) == 0 && mine) atomicAdd(trimmed, (unsigned long long)mine);
     }
 }
-// After the trim: every list is compacted to its alive entries (order kept) and written out as ids, m_pgrids also as ListKeys.
-__global__ void k_index_finalize(DParams prm, int vgrid, const csr_off_t* __restrict__ start, const unsigned long long* __restrict__ ids,
-                                 ListKey* __restrict__ key, int32_t* __restrict__ id32, int32_t* __restrict__ cnt_alive) {
+// After the trim: every list is compacted to its alive entries (order kept) at the FRONT of its own range -- the id to id32, the
+// (m_ncc, reference view) key of an m_pgrids entry over the sort key it replaces (a cell's thread reads position k >= b + n before it
+// writes position b + n) -- and counted.  k_index_pack then closes the gaps the trim left between the lists.
+__global__ void k_index_finalize(DParams prm, int vgrid, const csr_off_t* __restrict__ start, unsigned long long* __restrict__ ids,
+                                 int32_t* __restrict__ id32, int32_t* __restrict__ cnt_alive) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= prm.total_cells) return;
     const csr_off_t b = start[g], e = start[g + 1];
@@ -227,11 +229,29 @@ __global__ void k_index_finalize(DParams prm, int vgrid, const csr_off_t* __rest
         const int id = (int)(uint32_t)ids[k];
         const DPatch* p = prm.pool + id;
         if (!(p->flags & 1)) continue;
-        if (!vgrid) { ListKey lk; lk.ncc = p->ncc; lk.ref = p->images[0]; key[b + n] = lk; }  // m_vpgrids' readers want ids only
+        if (!vgrid) ids[b + n] = ((unsigned long long)(uint32_t)p->images[0] << 32) | (unsigned long long)__float_as_uint(p->ncc);  // m_vpgrids' readers want ids only
         id32[b + n] = id;
         ++n;
     }
     cnt_alive[g] = n;
+}
+// The lists of neighbouring cells end to end (start2 = the scan of the alive counts): Optim::check's findNeighbors reads the cells of a
+// grid row as ONE run of ids, which the gaps the trim left would break.
+__global__ void k_index_pack(DParams prm, const csr_off_t* __restrict__ start, const csr_off_t* __restrict__ start2, const int32_t* __restrict__ cnt_alive,
+                             const unsigned long long* __restrict__ ids, const int32_t* __restrict__ id32_in, ListKey* __restrict__ key, int32_t* __restrict__ id32_out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= prm.total_cells) return;
+    const csr_off_t b = start[g], b2 = start2[g];
+    const int n = cnt_alive[g];
+    for (int k = 0; k < n; ++k) {
+        id32_out[b2 + k] = id32_in[b + k];
+        if (key) {
+            const unsigned long long w = ids[b + k];
+            ListKey lk;
+            lk.ncc = __uint_as_float((uint32_t)w); lk.ref = (int32_t)(w >> 32);
+            key[b2 + k] = lk;
+        }
+    }
 }
 // PatchManager::updateDepthMaps, patch_manager.cpp:191-221, over the alive pool (Filter::setDepthMaps, filter.cpp:580-626)
 // A lane per patch, a wave per view (the four waves of a block share 64 consecutive patches and take the views in turn): patches that
@@ -930,7 +950,7 @@ __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* ki
     const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, nullptr};
     int* table = reinterpret_cast<int*>(s_lds);
     unsigned st4[4] = {0u, 0u, 0u, 0u};
-    const int n = find_neighbors<HCAP, false, true>(prm, wc, cx, c, table, 4.0f, 2, st4);
+    const int n = find_neighbors<HCAP, false>(prm, wc, cx, c, table, 4.0f, 2, st4);
     if (n < 0 || n > RCAP) {
         if (wc.lane == 0) {
             if (retry) retry[atomicAdd(nretry, 1)] = (int32_t)id;
@@ -1157,8 +1177,12 @@ void mvsk_index_fill_direct(const DParams& prm, int vgrid, const csr_off_t* star
 void mvsk_index_sort_trim(const DParams& prm, const csr_off_t* start, unsigned long long* ids, int do_trim, unsigned long long* trimmed, hipStream_t st) {
     hipLaunchKernelGGL(k_index_sort_trim, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, ids, do_trim, trimmed);
 }
-void mvsk_index_finalize(const DParams& prm, int vgrid, const csr_off_t* start, const unsigned long long* ids, ListKey* key, int32_t* id32, int32_t* cnt_alive, hipStream_t st) {
-    hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, vgrid, start, ids, key, id32, cnt_alive);
+void mvsk_index_finalize(const DParams& prm, int vgrid, const csr_off_t* start, unsigned long long* ids, int32_t* id32, int32_t* cnt_alive, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_finalize, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, vgrid, start, ids, id32, cnt_alive);
+}
+void mvsk_index_pack(const DParams& prm, const csr_off_t* start, const csr_off_t* start2, const int32_t* cnt_alive, const unsigned long long* ids, const int32_t* id32_in,
+                     ListKey* key, int32_t* id32_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_index_pack, dim3(nblk(prm.total_cells, 256)), dim3(256), 0, st, prm, start, start2, cnt_alive, ids, id32_in, key, id32_out);
 }
 void mvsk_depth_maps(const DParams& prm, unsigned long long* dp, const uint32_t* dirty, hipStream_t st) {
     if (prm.pool_n > 0) hipLaunchKernelGGL(k_depth_maps, dim3(nblk(prm.pool_n, 64)), dim3(256), 0, st, prm, dp, dirty);

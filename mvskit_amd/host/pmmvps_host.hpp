@@ -212,7 +212,7 @@ public:
     string m_commIdFile;
     unsigned long long m_jobNonce = 0;  // the same on every rank of a job (0: MVS_JOB_NONCE from the environment, else the id file's age decides)
     long long m_startedNs = 0;          // wall clock when this rank's job began (0: a minute before joinRanks)
-    bool m_strictListCap = false;       // true: init fails when the data set has more views than the linked engine's lists hold
+    bool m_strictListCap = true;        // init fails when the data set has more views than the linked engine's lists hold (false: a warning, and lists are cut)
 
     int m_nimages = 0, m_nillums = 1;
     vector<int> m_images;
