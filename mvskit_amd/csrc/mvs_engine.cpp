@@ -1440,7 +1440,10 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
         filter_fault_point(fr, 3);
         if (filter_exchange(fr, true, false)) break;
         FR(apply_kills(e, &rem[2], true));
-        if (rem[2] > 0) { if (filter_rebuild(fr, 1, true, true, 2)) break; }
+        // filterNeighbor removes a handful of patches (46 of 6 M in a second call at 1080p): m_pgrids is not rebuilt for them -- its one
+        // reader left, filterSmallGroups, skips a listed patch that is dead (k_groups_edges) -- while m_vpgrids is, because the removals
+        // can ADD memberships (a patch becomes visible where its occluder went)
+        if (rem[2] > 0) { if (filter_rebuild(fr, 1, false, true, 2)) break; }
         {                                                                              // filterSmallGroups (replicated: every rank on the whole pool)
             int64_t alive = 0;
             FR(mvs_engine_num_patches(e, &alive));

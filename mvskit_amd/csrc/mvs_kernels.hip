@@ -1043,7 +1043,10 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
         // two patches that hang on the same node are in one set already: one load instead of the predicate and the two root searches
         // of a union -- the common case once the large component has formed and its paths are short
         if (MODE != 2 && __atomic_load_n(&parent[eid], __ATOMIC_RELAXED) == __atomic_load_n(&parent[id], __ATOMIC_RELAXED)) return;
-        const PGeo q = load_geo(prm.pool + eid);  // only for the entries the same-set test lets through
+        // (only for the entries the same-set test lets through)  A listed patch may be dead: the m_pgrids lists are not rebuilt after
+        // Filter::filterNeighbor's handful of removals (mvs_engine_filter) -- its flags lie in the line that holds its geometry
+        if (!(prm.pool[eid].flags & 1)) return;
+        const PGeo q = load_geo(prm.pool + eid);
         if (!is_neighbor(prm, me, q, 1.0f /* m_neighborThreshold2, pmmvps.cpp:61 */)) return;
         if (MODE == 0) uf_union(parent, (int)id, eid);
         else if (MODE == 1) {

@@ -2,7 +2,7 @@
 # tools/refresh_manyview.sh [round]: the many-view part of tools/refresh_profiles.sh alone (48 x 960x540 on the 32- and 64-view builds:
 # bench line + SQ counters each), into gpurun_out/profiles_new/
 set -e
-R=${1:-r03}
+R=${1:-r04}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp

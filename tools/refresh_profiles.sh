@@ -2,7 +2,7 @@
 # tools/refresh_profiles.sh [round]: on a GPU box, regenerates what profiles/ holds for the current build
 # (run through gpurun; copies land in gpurun_out/profiles_new/, to be moved into profiles/ after review)
 set -e
-R=${1:-r03}
+R=${1:-r04}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -25,14 +25,5 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_mix.py $(find $out/mixa $out/mixb $out/mixc $out/mixd -name "*counter_collection.csv") > $out/${R}_pmc_mix_k_sweep.json
 python3 tools/pmc_sq.py $(find $out/sq -name "*counter_collection.csv" | head -1) > $out/${R}_pmc_sq_k_sweep.json
-echo "== many views: 48 x 960x540 on the 32-view and the 64-view build"
-M="--views 48 --width 960 --height 540"
-timeout -k 10 300 $B $M --list-cap 32 --cpu-seconds 0 > $out/${R}_bench_48x540p_cap32.json 2> $out/${R}_bench_48x540p_cap32.log
-timeout -k 10 300 $B $M --cpu-seconds 0 > $out/${R}_bench_48x540p.json 2> $out/${R}_bench_48x540p.log
-cd /tmp
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/sq48 -o sq48 -- $B $M --list-cap 32 --cpu-seconds 0 > $out/sq48.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/sq48c64 -o sq48c64 -- $B $M --cpu-seconds 0 > $out/sq48c64.log 2>&1
-cd $GRAFT_REPO_ROOT
-python3 tools/pmc_sq.py $(find $out/sq48 -name "*counter_collection.csv" | head -1) > $out/${R}_pmc_sq_k_sweep_48x540p_cap32.json
-python3 tools/pmc_sq.py $(find $out/sq48c64 -name "*counter_collection.csv" | head -1) > $out/${R}_pmc_sq_k_sweep_48x540p_cap64.json
+# (the many-view part -- 48 x 960x540 on the 32- and the 64-view build -- is tools/refresh_manyview.sh: its own gpurun call)
 find $out -name "*.csv" | head -40
