@@ -224,7 +224,8 @@ def run_config4(log_fn):
         sweep_ms += t["sweep_ms"]; index_ms += t["index_ms"]; commit_ms += t["commit_ms"]; launches += t["sweep_launches"]; filter_ms += fs["total_ms"]
         alive = e.num_patches()
         its.append({"iteration": it, "patches": c["patches"], "inserted": c["inserted"], "replaced": c["replaced"], "trimmed": c["trimmed"], "check_rejected_or_failed": c["fail1"],
-                    "propagate_ms": 1000.0 * (tb - ta), "sweep_ms": t["sweep_ms"], "index_ms": t["index_ms"], "filter_ms": fs["total_ms"], "filter_removed": removed,
+                    "propagate_ms": 1000.0 * (tb - ta), "sweep_ms": t["sweep_ms"], "index_ms": t["index_ms"], "filter_ms": fs["total_ms"],
+                    "filter_stage_ms": {k: fs[k] for k in ("outside_ms", "exact_ms", "neighbor_ms", "groups_ms", "rebuild_ms")}, "filter_removed": removed,
                     "pool_alive": alive, "hbm_used_GiB": (free0 - free1) / 2 ** 30, "check_retried_cells": t["check_retried_cells"]})
         log_fn(f"config4 iter {it}: {its[-1]}")
     e.close()

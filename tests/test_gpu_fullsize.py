@@ -269,7 +269,8 @@ def test_config4_48_views_4k_five_iterations(scene_48x4k):
         assert c["patches"] > 4_000_000 and c["inserted"] > 2_000_000, (it, c)
         assert all(v >= 0 for v in f.values())
         log.append({"iteration": it, "counters": c, "propagate_s": t1 - t0, "timing_ms": t, "filter_removed": f, "filter_s": t2 - t1,
-                    "filter_total_ms": fs["total_ms"], "pool_alive": e.num_patches(), "hbm_used_GiB": (free0 - free1) / 2 ** 30})
+                    "filter_total_ms": fs["total_ms"], "filter_stage_ms": {k: fs[k] for k in ("outside_ms", "exact_ms", "neighbor_ms", "groups_ms", "rebuild_ms")},
+                    "pool_alive": e.num_patches(), "hbm_used_GiB": (free0 - free1) / 2 ** 30})
     assert log[1]["counters"]["fail1"] > 0 or log[2]["counters"]["fail1"] > 0  # Optim::check (m_depth >= 2) rejects something at this size too
     assert sum(sum(l["filter_removed"].values()) for l in log) > 0
     p = e.patches()
