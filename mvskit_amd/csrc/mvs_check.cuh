@@ -18,17 +18,12 @@ namespace mvsdev {
 // the accepted ids compacted to its front -- the 3 floats per neighbour filterQuad keeps, stored behind the ids.
 // 2048 slots (at most 7/8 visited) and 576 neighbours fit 9472 B, which with the 768 B of static LDS is 10 KB per wave:
 // 16 waves per CU.  The oracle picks the table size by the same rule (engine_neighbor_order).
-#if MVS_LISTCAP > 32
-// the 64-view build: its dynamic LDS is sized by setRefImage's chunk of 32 textures (22 KB), so Optim::check's set can be twice as
-// large at no cost -- 64 views x 25 cells x two lists meet many more distinct patches (the oracle's rule: list_cap > 32)
-#define MVS_HASH_CAP 4096
-#define MVS_ROW_CAP 1152
-#define MVS_CHECK_LDS_FLOATS 4672
-#else
+// all three builds: a 2048-slot first tier (the many-view builds, which meet more patches, lean on the second tier more often; the
+// oracle's rule: "the small set if it fits, else 16384").  Rounds 3-4 gave the 64-view build 4096 slots, which its 22 KB of LDS per
+// wave had room for; with 16-view chunks of textures it runs in the 12 KB of the other builds.
 #define MVS_HASH_CAP 2048
 #define MVS_ROW_CAP 576
 #define MVS_CHECK_LDS_FLOATS 2368
-#endif
 // the id set (HCAP slots), or -- the accepted ids compacted to its front -- RCAP ids rounded up to 64, 3 floats per neighbour behind them
 // and the 20 doubles of filterQuad's normal equations (+ alignment): whichever is larger
 #define MVS_SET_ROWS_FLOATS(RCAP) ((((RCAP) + 63) & ~63) + 3 * (RCAP) + 64)

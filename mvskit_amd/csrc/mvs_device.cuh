@@ -695,43 +695,53 @@ DEV void cls_raw(const ClsPend& p, unsigned cs, float& r, float& g, float& b) { 
 #define MVS_PAIR_MFMA (MVS_LISTCAP > 16)  // setRefImage's pair sums on the matrix cores (the 32- and 64-view builds)
 #endif
 #if MVS_PAIR_MFMA
-// The Gram matrix G[a][b] = sum(k) t_a[k] t_b[k] of the kept textures is taken WHILE the views are sampled, in two chunks of
-// MVS_GRAM_CH views, so that only one chunk of textures lies in LDS at a time (the textures of a whole 32- or 64-view list were what
-// held these builds at one or two waves per SIMD).  Chunk A's textures are read once into registers in MFMA operand layout before
-// chunk B overwrites them; the tiles A x A, A x B, B x B each run down the k-ordered chain acc = fma(t_a[k], t_b[k], acc), which is
-// what v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32 compute.  G then replaces the textures in LDS (MVS_GRAM_LD floats per row).
-#define MVS_GRAM_CH (MVS_LISTCAP / 2)
-#define MVS_GRAM_LD MVS_LISTCAP
-#define MVS_GRAM_KK (MVS_GRAM_CH == 16 ? 4 : 2)                 // k values per MFMA: 16x16x4 or 32x32x2
-#define MVS_GRAM_KS ((147 + MVS_GRAM_KK - 1) / MVS_GRAM_KK)      // MFMAs per tile for a 7x7 window (3 * 49 elements): 37 or 74
-#define MVS_GRAM_NACC (MVS_GRAM_CH == 16 ? 4 : 16)               // accumulator registers of a tile
+// The Gram matrix G[a][b] = sum(k) t_a[k] t_b[k] of the kept textures is taken WHILE the views are sampled, in chunks of 16 views, so
+// that only one chunk of textures lies in LDS at a time (the textures of a whole 32- or 64-view list were what held these builds at one
+// or two waves per SIMD).  Every 16 x 16 tile runs down the k-ordered chain acc = fma(t_a[k], t_b[k], acc), which is what
+// v_mfma_f32_16x16x4_f32 computes (37 of them for a 7 x 7 window).  G then replaces the textures in LDS (prm.gram_ld floats per row).
+// The MFMA operands of a finished chunk go to PRIVATE memory -- a dynamically indexed per-lane array, i.e. the compiler's scratch
+// segment: L1 / L2 resident, no slot bookkeeping, each lane reads back exactly what it wrote -- and come back eight k-steps at a time:
+//   MVS_GRAM_SCRATCH 1 (the 32-view build): the tiles of a chunk with the earlier chunks are taken as soon as the chunk is sampled,
+//     the accumulators of all tiles (3 x 4 registers) stay in registers until the list is through;
+//   MVS_GRAM_SCRATCH 2 (the 64-view build): nothing of the matrix lives in registers while the views are sampled -- all chunks'
+//     operands go out, and when the list is through the (up to 10) tiles are taken one after the other from there (4 accumulator
+//     registers): 44 spilled registers at three waves per SIMD where the first form spills 146.
+// Rounds 3-4 kept chunk A (half the list) in 37 / 74 registers while chunk B was sampled: the 64-view build then needed the 256 VGPRs
+// and the 22 KB of LDS of two waves per SIMD and ran at 11.5 M patches/s on 48 x 540p; 13.6 M with form 1, 14.5 M with form 2
+// (gpurun_out/r04l, r04m); the 32-view build 17.4 M either way, 16.6 M with form 2.
+#ifndef MVS_GRAM_SCRATCH
+#define MVS_GRAM_SCRATCH (MVS_LISTCAP > 32 ? 2 : 1)
+#endif
+#define MVS_GRAM_CH 16
+#define MVS_GRAM_NCH (MVS_LISTCAP / 16)                          // chunks at most: 2 or 4 (1 in an experimental 16-view build)
+#define MVS_GRAM_NT (MVS_GRAM_NCH * (MVS_GRAM_NCH + 1) / 2)     // tiles (p <= c): 3 or 10
+#define MVS_GRAM_KSP 40                                         // MVS_GRAM_KS rounded up to groups of 8 k-steps
+#define MVS_GRAM_T(p, c) ((c) * ((c) + 1) / 2 + (p))
+#define MVS_GRAM_KK 4                                           // k values per MFMA (16x16x4)
+#define MVS_GRAM_KS ((147 + MVS_GRAM_KK - 1) / MVS_GRAM_KK)      // MFMAs per tile for a 7x7 window (3 * 49 elements): 37
+#define MVS_GRAM_NACC 4                                         // accumulator registers of a tile
 typedef float gram_acc_t __attribute__((ext_vector_type(MVS_GRAM_NACC)));
-DEV gram_acc_t gram_mfma(float a, float b, gram_acc_t c) {
-#if MVS_LISTCAP == 32
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#else
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-#endif
-}
+DEV gram_acc_t gram_mfma(float a, float b, gram_acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // accumulator register r of lane l holds tile element (row, col)
-DEV int gram_col(int lane) { return lane & (MVS_GRAM_CH - 1); }
-DEV int gram_row(int lane, int r) {
-#if MVS_LISTCAP == 32
-    return (lane >> 4) * 4 + r;
-#else
-    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#endif
-}
+DEV int gram_col(int lane) { return lane & 15; }
+DEV int gram_row(int lane, int r) { return (lane >> 4) * 4 + r; }
+template <int N> struct GramIC { static constexpr int value = N; };
 #endif
 template <bool PIV = false>
 DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmask_t (&okm)[1], float& incc_l, float* piv = nullptr,
                     float* texs = nullptr, int tstride = 0, float* ssd_out = nullptr) {
 #if MVS_PAIR_MFMA
-    // texs != nullptr: the Gram matrix of the centred textures is left at texs[a * MVS_GRAM_LD + b] (see MVS_GRAM_CH above)
-    float ta[MVS_GRAM_KS];  // chunk A in MFMA operand layout: lane l holds t_{l % CH}[KK s + l / CH] in ta[s]
-    gram_acc_t gAA, gAB, gBB;
+    // texs != nullptr: the Gram matrix of the centred textures is left at texs[a * LD + b] (see MVS_GRAM_CH above)
+#if MVS_GRAM_SCRATCH == 2
+    float gops[MVS_GRAM_NCH * MVS_GRAM_KSP];           // private memory: the MFMA operands of ALL chunks (lane l: t_{l % 16}[4 s + l / 16])
+#elif MVS_GRAM_SCRATCH
+    gram_acc_t gacc[MVS_GRAM_NT];                      // tile (p, c), p <= c, at MVS_GRAM_T(p, c)
+    float gops[(MVS_GRAM_NCH > 1 ? MVS_GRAM_NCH - 1 : 1) * MVS_GRAM_KSP];  // private memory: the MFMA operands of the finished chunks (lane l: t_{l % 16}[4 s + l / 16]); unused with one chunk
 #pragma unroll
-    for (int r = 0; r < MVS_GRAM_NACC; ++r) { gAA[r] = 0.0f; gAB[r] = 0.0f; gBB[r] = 0.0f; }
+    for (int q = 0; q < MVS_GRAM_NT; ++q)
+#pragma unroll
+        for (int r = 0; r < MVS_GRAM_NACC; ++r) gacc[q][r] = 0.0f;
+#endif
     const int gK = 3 * prm.wsz, gtp = 3 * tstride;
     const int gk0 = wc.lane / MVS_GRAM_CH;                       // this lane's k within an MFMA
     const float* const grow = texs + (wc.lane & (MVS_GRAM_CH - 1)) * gtp;  // this lane's view of the chunk in LDS
@@ -855,73 +865,142 @@ DEV void eval_views(const DParams& prm, WaveCtx& wc, const Frame& f, int n, vmas
         }
 #endif
     };
-#if MVS_PAIR_MFMA
-    // chunk A is complete after `tdone` rounds (or the list ends inside it): to registers, and A x A
-    auto gram_chunk_a = [&](const int tdone) {
-        __syncthreads();
-        // rows of chunk A that no round wrote (list shorter than the chunk) must read as zeros
-        for (int vz = 4 * tdone + (wc.lane >> 4); vz < MVS_GRAM_CH; vz += 4)
-            for (int q = lc; q < gtp; q += 16) texs[vz * gtp + q] = 0.0f;
-        __syncthreads();
-#pragma unroll
-        for (int sI = 0; sI < MVS_GRAM_KS; ++sI) {
-            const int k = MVS_GRAM_KK * sI + gk0;
-            ta[sI] = k < gK ? grow[k] : 0.0f;
-            gAA = gram_mfma(ta[sI], ta[sI], gAA);
-        }
-        __syncthreads();
-    };
-    // chunk B: B x B from LDS, A x B with chunk A from the registers
-    auto gram_chunk_b = [&]() {
-        __syncthreads();
-        for (int vz = 4 * rounds - MVS_GRAM_CH + (wc.lane >> 4); vz < MVS_GRAM_CH; vz += 4)
-            for (int q = lc; q < gtp; q += 16) texs[vz * gtp + q] = 0.0f;
-        __syncthreads();
-#pragma unroll
-        for (int sI = 0; sI < MVS_GRAM_KS; ++sI) {
-            const int k = MVS_GRAM_KK * sI + gk0;
-            const float tb = k < gK ? grow[k] : 0.0f;
-            gBB = gram_mfma(tb, tb, gBB);
-            gAB = gram_mfma(ta[sI], tb, gAB);
-        }
-        __syncthreads();
-    };
-    // One loop with the two blocks inside it (32-view build), or two loops, so that chunk A's registers are alive only while chunk B
-    // is sampled (64-view build: 74 of them): measured on the 48-view scene, 14.6 against 13.5 M patches/s for the 32-view build and
-    // 10.1 against 10.6 M for the 64-view build.
+#if MVS_PAIR_MFMA && MVS_GRAM_SCRATCH == 2
+    // Variant: NOTHING of the Gram matrix lives in registers while the views are sampled.  A finished chunk's operands go to private
+    // memory; when the list is through, the tiles are taken one after the other from there (four accumulator registers) and written
+    // to LDS over the textures.
     if (texs) {
-        const int tA = min(rounds, MVS_GRAM_CH / 4);
-#if MVS_LISTCAP > 32
-        for (int t = 0; t < tA; ++t) round_body(t);
-        gram_chunk_a(tA);
-        if (rounds > tA) {
-            for (int t = tA; t < rounds; ++t) round_body(t);
-            gram_chunk_b();
-        }
-#else
+        int ch = 0;
         for (int t = 0; t < rounds; ++t) {
             round_body(t);
-            if (t + 1 == tA) gram_chunk_a(tA);
-            if (t + 1 == rounds && rounds > tA) gram_chunk_b();
-        }
-#endif
-    } else
-#endif
-    for (int t = 0; t < rounds; ++t) round_body(t);
-#if MVS_PAIR_MFMA
-    if (texs) {  // the tiles to LDS over the textures: G[a][b], a and b in the order of this evaluation's list
-        __syncthreads();
-        const int col = gram_col(wc.lane);
+            if ((t & 3) == 3 || t + 1 == rounds) {
+                const int rc = (t & 3) + 1;
+                __syncthreads();
+                for (int vz = 4 * rc + (wc.lane >> 4); vz < MVS_GRAM_CH; vz += 4)
+                    for (int q = lc; q < gtp; q += 16) texs[vz * gtp + q] = 0.0f;
+                __syncthreads();
+#pragma unroll 1
+                for (int s0 = 0; s0 < MVS_GRAM_KSP; s0 += 8) {
+                    float tb[8];
 #pragma unroll
-        for (int r = 0; r < MVS_GRAM_NACC; ++r) {
-            const int row = gram_row(wc.lane, r);
-            texs[row * MVS_GRAM_LD + col] = gAA[r];
-            texs[row * MVS_GRAM_LD + MVS_GRAM_CH + col] = gAB[r];
-            texs[(MVS_GRAM_CH + col) * MVS_GRAM_LD + row] = gAB[r];
-            texs[(MVS_GRAM_CH + row) * MVS_GRAM_LD + MVS_GRAM_CH + col] = gBB[r];
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = MVS_GRAM_KK * (s0 + j) + gk0;
+                        tb[j] = (s0 + j < MVS_GRAM_KS && k < gK) ? grow[k] : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gops[ch * MVS_GRAM_KSP + s0 + j] = tb[j];
+                }
+                __syncthreads();
+                ++ch;
+            }
+        }
+        const int LD = prm.gram_ld, col = gram_col(wc.lane);
+#pragma unroll 1
+        for (int c2 = 0; c2 < ch; ++c2) {
+#pragma unroll 1
+            for (int pq = 0; pq <= c2; ++pq) {
+                gram_acc_t acc;
+#pragma unroll
+                for (int r = 0; r < MVS_GRAM_NACC; ++r) acc[r] = 0.0f;
+#pragma unroll 1
+                for (int s0 = 0; s0 < MVS_GRAM_KSP; s0 += 8) {
+                    float a8[8], b8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { a8[j] = gops[pq * MVS_GRAM_KSP + s0 + j]; b8[j] = gops[c2 * MVS_GRAM_KSP + s0 + j]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (s0 + j < MVS_GRAM_KS) acc = gram_mfma(a8[j], b8[j], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < MVS_GRAM_NACC; ++r) {
+                    const int rw = gram_row(wc.lane, r);
+                    texs[(MVS_GRAM_CH * pq + rw) * LD + MVS_GRAM_CH * c2 + col] = acc[r];
+                    if (pq != c2) texs[(MVS_GRAM_CH * c2 + col) * LD + MVS_GRAM_CH * pq + rw] = acc[r];
+                }
+            }
+        }
+        // rows / columns of chunks the list never reached are never read (set_ref_image reads indices < n_eval)
+        __syncthreads();
+    } else
+        for (int t = 0; t < rounds; ++t) round_body(t);
+#elif MVS_PAIR_MFMA && MVS_GRAM_SCRATCH
+    // chunk C is complete after `rc` rounds of its own (or the list ends inside it): its diagonal tile from LDS, its tiles with the
+    // earlier chunks p < C (their operands back from private memory, eight k-steps in flight), and its own operands out
+    auto chunk_done = [&](auto Cc, const int rc) {
+        constexpr int C = decltype(Cc)::value;
+        __syncthreads();
+        // rows of the chunk that no round wrote (the list ends inside it) must read as zeros
+        for (int vz = 4 * rc + (wc.lane >> 4); vz < MVS_GRAM_CH; vz += 4)
+            for (int q = lc; q < gtp; q += 16) texs[vz * gtp + q] = 0.0f;
+        __syncthreads();
+#pragma unroll 1
+        for (int s0 = 0; s0 < MVS_GRAM_KSP; s0 += 8) {
+            float tb[8], ap[C > 0 ? C : 1][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = MVS_GRAM_KK * (s0 + j) + gk0;
+                tb[j] = (s0 + j < MVS_GRAM_KS && k < gK) ? grow[k] : 0.0f;
+#pragma unroll
+                for (int pq = 0; pq < C; ++pq) ap[pq][j] = gops[pq * MVS_GRAM_KSP + s0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (s0 + j < MVS_GRAM_KS) {  // wave-uniform
+                    gacc[MVS_GRAM_T(C, C)] = gram_mfma(tb[j], tb[j], gacc[MVS_GRAM_T(C, C)]);
+#pragma unroll
+                    for (int pq = 0; pq < C; ++pq) gacc[MVS_GRAM_T(pq, C)] = gram_mfma(ap[pq][j], tb[j], gacc[MVS_GRAM_T(pq, C)]);
+                }
+            }
+            if (C < MVS_GRAM_NCH - 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gops[(C < MVS_GRAM_NCH - 1 ? C : 0) * MVS_GRAM_KSP + s0 + j] = tb[j];
+            }
         }
         __syncthreads();
-    }
+    };
+    if (texs) {
+        int ch = 0;
+        for (int t = 0; t < rounds; ++t) {
+            round_body(t);
+            if ((t & 3) == 3 || t + 1 == rounds) {
+                const int rc = (t & 3) + 1;
+                switch (ch) {
+                    case 0: chunk_done(GramIC<0>{}, rc); break;
+#if MVS_GRAM_NCH > 1
+                    case 1: chunk_done(GramIC<1>{}, rc); break;
+#endif
+#if MVS_GRAM_NCH > 2
+                    case 2: chunk_done(GramIC<2>{}, rc); break;
+                    default: chunk_done(GramIC<3>{}, rc); break;
+#else
+                    default: break;
+#endif
+                }
+                ++ch;
+            }
+        }
+        // the tiles to LDS over the textures: G[a][b], a and b in the order of this evaluation's list (LD = prm.gram_ld columns)
+        __syncthreads();
+        const int LD = prm.gram_ld, col = gram_col(wc.lane);
+#pragma unroll
+        for (int c2 = 0; c2 < MVS_GRAM_NCH; ++c2) {
+            if (MVS_GRAM_CH * c2 >= LD) continue;  // chunks the data set's list length never reaches (wave-uniform)
+#pragma unroll
+            for (int pq = 0; pq <= c2; ++pq) {
+#pragma unroll
+                for (int r = 0; r < MVS_GRAM_NACC; ++r) {
+                    const int rw = gram_row(wc.lane, r);
+                    const float gv = gacc[MVS_GRAM_T(pq, c2)][r];
+                    texs[(MVS_GRAM_CH * pq + rw) * LD + MVS_GRAM_CH * c2 + col] = gv;
+                    if (pq != c2) texs[(MVS_GRAM_CH * c2 + col) * LD + MVS_GRAM_CH * pq + rw] = gv;
+                }
+            }
+        }
+        __syncthreads();
+    } else
+        for (int t = 0; t < rounds; ++t) round_body(t);
+#else
+    for (int t = 0; t < rounds; ++t) round_body(t);
 #endif
     // lane 16 (v & 3) + (v >> 2): 1 / msd and the INCC of view v; then to view lane v
     const float inv_l = inv_msd(prm, ssd_l);
@@ -1423,6 +1502,7 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     // G[a][b] into the robust INCC of the pair (both triangles); `ne` = the list length of that evaluation, its views' 1 / msd and
     // sampled bits by evaluation-time index.
     {
+        const int MVS_GRAM_LD = prm.gram_ld;  // the data set's list length rounded up to a chunk
         const int ne = kt ? kt->n_eval : n;
         const float inv_e = kt ? inv_msd(prm, kt->ssd) : inv_l;
         const vmask_t ok_e = kt ? kt->okm : okmask;
@@ -1465,6 +1545,7 @@ DEV void set_ref_image(const DParams& prm, WaveCtx& wc, float* texs, int tstride
     float acc = 0.0f;
 #if MVS_PAIR_MFMA
     {
+        const int MVS_GRAM_LD = prm.gram_ld;
         const int oi = wc.lane < n ? orig : 0;  // where view i sat in the evaluation whose matrix this is
         for (int j = 0; j < n; ++j) {
             const float v = texs[oi * MVS_GRAM_LD + rli(orig, j)];

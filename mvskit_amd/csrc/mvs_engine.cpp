@@ -243,6 +243,7 @@ void derive_params(mvs_engine* e) {  // PmMvps::init, pmmvps.cpp:32-36,54-67
     p.neighborThreshold = 0.5f; p.neighborThreshold1 = 1.0f;
     p.quadThreshold = c.quadThreshold;
     p.list_n = std::min<int>(MVS_LISTCAP, c.nviews);
+    p.gram_ld = (p.list_n + 15) / 16 * 16;
 }
 
 void invert3(const float* P, float* Minv) {  // Matrix3f::inverse (camera.cpp:304,335), in double

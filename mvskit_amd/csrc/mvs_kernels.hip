@@ -423,11 +423,6 @@ __global__ void k_job_cuts(const int32_t* __restrict__ scan, int64_t njobs, int 
     }
 }
 
-#if !defined(MVS_SWEEP_WAVES) && MVS_LISTCAP > 32
-// the 64-view build: 22 KB of LDS per wave (one chunk of 32 textures) allow 7 waves per CU whatever the registers, and chunk A of
-// the Gram matrix waits in 74 registers: the allocator gets the 256 VGPRs of two waves per SIMD
-#define MVS_SWEEP_WAVES 2
-#endif
 #ifndef MVS_SWEEP_WAVES
 #define MVS_SWEEP_WAVES 3  // waves per SIMD the register allocator is asked to fit: 168 VGPRs (4 waves = 128 VGPRs spills ~110 of them; measured 19.4 vs 18.9 M patches/s)
 #endif
@@ -1207,7 +1202,7 @@ size_t mvsk_sweep_lds_bytes(const DParams& prm) {
     // in postProcess they lie behind the frame region (the evaluation that produces them publishes its frames there).
     // The 32- and 64-view builds keep one chunk of MVS_GRAM_CH views at a time and overlay the Gram matrix on it (mvs_device.cuh).
 #if MVS_PAIR_MFMA
-    const size_t tex_f = (size_t)MVS_GRAM_CH * 3 * prm.wsz, gram_f = (size_t)MVS_GRAM_LD * MVS_GRAM_LD;
+    const size_t tex_f = (size_t)MVS_GRAM_CH * 3 * prm.wsz, gram_f = (size_t)prm.gram_ld * prm.gram_ld;
     const size_t texs = MVS_FRAME1_LDS_BYTES + (tex_f > gram_f ? tex_f : gram_f) * sizeof(float);
 #else
     const size_t ln = (size_t)prm.list_n;  // min(MVS_LISTCAP, nviews): a 12-view data set keeps 12 textures, not 16
@@ -1274,7 +1269,7 @@ void mvsk_filter_outside(const DParams& prm, uint8_t* kill, int64_t first, int64
 // 9.5 KB per wave at 12 views -- the kernel waits on dependent gathers (vector ALU busy 37 %), so resident waves are what it lacks
 size_t mvsk_texs_lds_bytes(const DParams& prm) {
 #if MVS_PAIR_MFMA
-    const size_t tex_f = (size_t)MVS_GRAM_CH * 3 * prm.wsz, gram_f = (size_t)MVS_GRAM_LD * MVS_GRAM_LD;
+    const size_t tex_f = (size_t)MVS_GRAM_CH * 3 * prm.wsz, gram_f = (size_t)prm.gram_ld * prm.gram_ld;
     const size_t texs = MVS_FRAME1_LDS_BYTES + (tex_f > gram_f ? tex_f : gram_f) * sizeof(float);
 #else
     const size_t ln = (size_t)prm.list_n;

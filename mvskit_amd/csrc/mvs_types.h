@@ -72,7 +72,8 @@ struct DParams {
     float sortThreshold, ascaleConst, neighborThreshold, neighborThreshold1, quadThreshold;
     float inv_sz, inv_3sz;  // 1/wsize^2 and 1/(3 wsize^2)
     int32_t total_cells;
-    int32_t list_n;         // min(MVS_LISTCAP, nviews): no list is longer; sizes the kept textures of setRefImage in the 64-view build
+    int32_t list_n;         // min(MVS_LISTCAP, nviews): no list is longer; sizes the kept textures of setRefImage
+    int32_t gram_ld;        // many-view builds: row pitch of setRefImage's Gram matrix in LDS = list_n rounded up to a chunk of 16 views
     const DView* views;
     DPatch* pool;
     int64_t pool_n;

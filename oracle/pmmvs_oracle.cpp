@@ -1236,8 +1236,9 @@ void find_neighbors(const Scene& s, const Patch& p, std::vector<int>& nb, float 
     std::sort(nb.begin(), nb.end());
     nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
     if (s.cfg.sum_mode == ORC_SUM_TREE64) {
-        const bool wide = in_check && s.list_cap > 32;  /* the 64-view engine build gives Optim::check a 4096-slot set */
-        engine_neighbor_order(visited, nb, wide ? 4096 : 2048, wide ? 1152 : (in_check ? 576 : 448));  /* Filter::filterNeighbor: MVS_FILTER_ROW_CAP */
+        /* every engine build: a 2048-slot first tier (rounds 3-4 gave the 64-view build's Optim::check 4096 slots, which its 22 KB of LDS
+         * per wave had room for; with 16-view chunks of textures it runs in the 12 KB of the other builds), then 16384 */
+        engine_neighbor_order(visited, nb, 2048, in_check ? 576 : 448);  /* Filter::filterNeighbor: MVS_FILTER_ROW_CAP */
     }
 }
 
