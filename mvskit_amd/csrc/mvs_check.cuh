@@ -59,6 +59,16 @@ DEV const DPatch* patch_ptr(const DParams& prm, const CheckCtx& cx, int id) {
 // geometry of a patch needed by the neighbour predicates
 struct PGeo { F4 coord, normal; float dscale, ncc; int ref; };
 DEV PGeo load_geo(const DPatch* p) { return {ld4(p->coord), ld4(p->normal), p->dscale, p->ncc, (int)p->images[0]}; }
+// The same of pool patch `id`.  PK (Filter::run's stages, DParams::geo set): from the packed copy -- one 32-byte sector, and a byte for
+// the reference view where the caller uses it -- instead of the 96- to 192-byte record; what is not stored is what k_geo_pack verified
+// (coord.w == 1, normal.w == 0), so the values are the record's bit for bit.
+template <bool PK> DEV PGeo pool_geo(const DParams& prm, int id) {
+    if (PK) {
+        const float4 a = prm.geo[2 * (size_t)id], b = prm.geo[2 * (size_t)id + 1];
+        return {{a.x, a.y, a.z, 1.0f}, {b.x, b.y, b.z, 0.0f}, a.w, b.w, (int)prm.geo_ref[id]};
+    }
+    return load_geo(prm.pool + id);
+}
 
 // PmMvps::isNeighbor, pmmvps.cpp:117-147 (deg/rad typo at :124 kept)
 DEV int is_neighbor_h(const DParams& prm, const PGeo& l, const PGeo& r, float hunit, float thr) {
@@ -101,16 +111,16 @@ DEV ListRef cell_span(const DParams& prm, const CheckCtx& cx, int kind, int view
     if (kind == 0) return {prm.csr_id32 + prm.csr_start[g], prm.csr_cnt[g], false};
     return {prm.vcsr_id32 + prm.vcsr_start[g], prm.vcsr_cnt[g], false};
 }
-DEV PGeo entry_geo(const DParams& prm, const CheckCtx& cx, const ListRef& l, int j, int& id) {
+template <bool PK = false> DEV PGeo entry_geo(const DParams& prm, const CheckCtx& cx, const ListRef& l, int j, int& id) {
     if (l.live) { id = cx.live_ids[j]; return load_geo(patch_ptr(prm, cx, id)); }
     id = l.ids[j];
-    return load_geo(prm.pool + id);  // a snapshot list names pool patches only
+    return pool_geo<PK>(prm, id);  // a snapshot list names pool patches only
 }
 
 // Filter::computeGain, filter.cpp:108-146.  One lane per (view, list entry) pair -- a list holds at most
 // MAX_NUM_OF_PATCHES entries after the trim, so one or two rounds of 64 pairs cover all views -- and the per-view maxima
 // (a maximum does not depend on the order) are collected with LDS atomics.  tmp: MVS_LISTCAP ints of LDS.
-DEV void gain_part(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, const PGeo& me, bool visible_part, int* tmp, float& gain) {
+template <bool PK = false> DEV void gain_part(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, const PGeo& me, bool visible_part, int* tmp, float& gain) {
     const int nv = visible_part ? c.nvimg : c.nimg;
     if (nv == 0) return;
     int ln = 0, lcell = 0, lview = 0;  // view lane i: its cell list
@@ -140,7 +150,7 @@ DEV void gain_part(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, co
         if (t < total) {
             const ListRef l = cell_span(prm, cx, 0, v, cell);
             int id;
-            const PGeo g = entry_geo(prm, cx, l, j, id);
+            const PGeo g = entry_geo<PK>(prm, cx, l, j, id);
             bool counts = true;
             if (visible_part) counts = pd < dot4(ld4((prm.views + v)->oaxis), g.coord);
             if (counts && !is_neighbor(prm, me, g, prm.neighborThreshold1)) {
@@ -153,11 +163,11 @@ DEV void gain_part(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, co
     const float vmax = wc.lane < MVS_LISTCAP ? __int_as_float(tmp[wc.lane]) : 0.0f;
     for (int i = 0; i < nv; ++i) gain -= rlf(vmax, i);
 }
-DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* tmp) {
+template <bool PK = false> DEV float compute_gain(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* tmp) {
     const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
     float gain = score2(c, prm.nccThreshold);
-    gain_part(prm, wc, cx, c, me, false, tmp, gain);
-    gain_part(prm, wc, cx, c, me, true, tmp, gain);
+    gain_part<PK>(prm, wc, cx, c, me, false, tmp, gain);
+    gain_part<PK>(prm, wc, cx, c, me, true, tmp, gain);
     return gain;
 }
 
@@ -205,9 +215,23 @@ DEV bool set_insert_from(int* table, unsigned mask, int k, unsigned p) {
     return false;
 }
 #define MVS_FN_INFLIGHT 4  // id loads in flight in the row walk (8, 16, 32 measured the same or slower)
-template <int HCAP, bool G = false>
+// inclusive running maximum over the lanes (values >= -1): four row_shr steps inside the rows of 16, then row_bcast:15 / :31 carry the rows' ends on
+DEV int wave_max_scan(int x) {
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+#ifndef MVS_FN_MARKS
+#define MVS_FN_MARKS 1
+#endif
+// `marks` (MK): 64 ints of LDS outside the table -- the run of an id by marks and a running maximum instead of a binary search, see below
+template <int HCAP, bool G = false, bool PK = false, bool MK = false>
 DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, int* table, float scale, int margin,
-                       unsigned* stats = nullptr) {
+                       unsigned* stats = nullptr, int* marks = nullptr) {
     const PGeo me{c.coord, c.normal, c.dscale, c.ncc, rli(c.img, 0)};
     // Propagate::computeRadius, propagate.cpp:474-481: the second smallest unit
     float u = __int_as_float(0x7f800000);
@@ -289,8 +313,68 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
         const int total = __builtin_amdgcn_readlane(P, 63);
         P -= len;
         if (wc.lane == 0) n_entries += (unsigned)total;
+        // (MK) The run of id k without a search per id: every run marks the position it begins at -- its lane number, a byte, in a
+        // 256-position window laid out so that lane l reads positions l, 64 + l, 128 + l, 192 + l as ONE dword -- and the run of a
+        // position is the running maximum of the marks up to it (runs begin in lane order): four DPP scans and three carries for 256
+        // ids, where the binary search over the running totals took six ds_bpermute round trips per 64.  What an id needs of its run
+        // is then one 64-bit value, the address its k is an index from (the live list: a tag and the LDS index).
+        unsigned blo = 0u, bhi = 0u;
+        if (MK) {
+            const unsigned long long base = src == 2 ? ((0x7fffffffull << 32) | (unsigned)(-P))
+                                                     : (unsigned long long)((long long)(uintptr_t)(src == 1 ? prm.vcsr_id32 : prm.csr_id32) + 4ll * (long long)(b - (csr_off_t)P));
+            blo = (unsigned)base; bhi = (unsigned)(base >> 32);
+        }
+        int carry = 0;
         for (int k0 = 0; k0 < total; k0 += 64 * MVS_FN_INFLIGHT) {
             int id[MVS_FN_INFLIGHT];
+            if (MK) {
+                static_assert(MVS_FN_INFLIGHT == 4, "one byte per 64 positions in a dword of marks");
+                marks[wc.lane] = -1;
+                const int pm = P - k0;
+                if (len > 0 && (unsigned)pm < 256u) reinterpret_cast<signed char*>(marks)[(pm & 63) * 4 + (pm >> 6)] = (signed char)wc.lane;
+                __syncthreads();
+                const int m4 = marks[wc.lane];
+                int run[4] = {(m4 << 24) >> 24, (m4 << 16) >> 24, (m4 << 8) >> 24, m4 >> 24};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) run[q] = wave_max_scan(run[q]);
+                run[0] = max(run[0], carry);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) run[q] = max(run[q], __builtin_amdgcn_readlane(run[q - 1], 63));
+                carry = __builtin_amdgcn_readlane(run[3], 63);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = k0 + 64 * q + wc.lane;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(run[q] << 2, (int)blo), hi = (unsigned)__builtin_amdgcn_ds_bpermute(run[q] << 2, (int)bhi);
+                    int v_id = MVS_SET_EMPTY;
+#if MVS_FN_MARKS == 2  // debugging: the address by the search as well; loads through that one and reports a difference
+                    {
+                        int lo2 = 0;
+                        for (int step = 32; step >= 1; step >>= 1) { const int pc = __shfl(P, lo2 + step); if (pc <= k) lo2 += step; }
+                        const csr_off_t bb = __shfl(b, lo2);
+                        const int pl = __shfl(P, lo2), sr = __shfl(src, lo2);
+                        if (k < total) {
+                            const int32_t* want = sr == 2 ? nullptr : (sr == 1 ? prm.vcsr_id32 : prm.csr_id32) + (bb + (k - pl));
+                            const int32_t* got = reinterpret_cast<const int32_t*>(((unsigned long long)hi << 32) | lo) + k;
+                            const bool livegot = live_i >= 0 && hi == 0x7fffffffu;
+                            if ((sr == 2) != livegot || (sr == 2 ? ((int)lo + k != k - pl) : (want != got)))
+                                printf("[marks] block %d lane %d k %d total %d run %d search %d sr %d hi %08x lo %08x want %p got %p live_i %d nrow_all %d r0 %d k0 %d\n", (int)blockIdx.x, wc.lane, k, total, run[q], lo2, sr, hi, lo, want, got, live_i, nrow_all, r0, k0);
+                            v_id = sr == 2 ? cx.live_ids[k - pl] : *want;
+                        }
+                    }
+#else
+                    // Two loads in their own address spaces.  As ONE generic pointer the compiler folds the "+ 64 q" of k into the flat
+                    // instruction's offset field, and the address without it lies below the LDS aperture for the first ids of the live list
+                    // (k - 64 q < P): the hardware picks the aperture before it adds the offset -- a memory aperture violation.
+                    if (k < total) {
+                        typedef const int32_t __attribute__((address_space(1)))* gptr_i32;
+                        typedef const int __attribute__((address_space(3)))* lptr_i32;
+                        if (live_i >= 0 && hi == 0x7fffffffu) v_id = ((lptr_i32)cx.live_ids)[(int)lo + k];
+                        else v_id = ((gptr_i32)(((unsigned long long)hi << 32) | lo))[k];
+                    }
+#endif
+                    id[q] = v_id;
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < MVS_FN_INFLIGHT; ++q) {
                 const int k = k0 + 64 * q + wc.lane;
@@ -341,13 +425,14 @@ DEV int find_neighbors(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx
     __syncthreads();
     int count = 0;
     int v_next = wc.lane < visited ? tb_ld<G>(table, wc.lane) : -1;
-    PGeo g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));  // lanes past the end read record 0: harmless, unused
+    auto geo_of = [&](int id) { return PK ? pool_geo<true>(prm, id) : load_geo(patch_ptr(prm, cx, id)); };  // PK: no live list, no staged records
+    PGeo g_next = geo_of(max(v_next, 0));  // lanes past the end read record 0: harmless, unused
     for (int b0 = 0; b0 < visited; b0 += 64) {
         const int v_cur = v_next;
         const PGeo g_cur = g_next;
         if (b0 + 64 < visited) {
             v_next = b0 + 64 + wc.lane < visited ? tb_ld<G>(table, b0 + 64 + wc.lane) : -1;
-            g_next = load_geo(patch_ptr(prm, cx, max(v_next, 0)));
+            g_next = geo_of(max(v_next, 0));
         }
         const bool acc = v_cur >= 0 && is_neighbor_radius(prm, me, g_cur, unit, thr, radius);
         const unsigned long long m = ballot(acc);
@@ -455,7 +540,7 @@ DEV double shfl_f64(double x, int src) {
 // Filter::filterQuad, filter.cpp:329-392.  nb = sorted ids in LDS (n of them); rows = LDS scratch of 3*n floats
 // (fx, fy, fz per neighbour).  The three sums over the neighbours (mean distance, normal equations, residual) are
 // lane-strided partial sums (lane l takes neighbours l, l+64, ...) followed by a wave butterfly.
-template <bool G = false>
+template <bool G = false, bool PK = false>
 DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, const Cand& c, const int* nb, int n, float* rows, double* sums_lds = nullptr) {
     F4 xdir, ydir;
     ortho(c.normal, xdir, ydir);
@@ -463,7 +548,11 @@ DEV int filter_quad(const DParams& prm, const WaveCtx& wc, const CheckCtx& cx, c
     // in the rows for the division by h
     float hp = 0.0f;
     for (int t = wc.lane; t < n; t += 64) {
-        const F4 diff = sub4(ld4(patch_ptr(prm, cx, tb_ld<G>(nb, t))->coord), c.coord);
+        const int qid = tb_ld<G>(nb, t);
+        F4 qc;
+        if (PK) { const float4 a = prm.geo[2 * (size_t)qid]; qc = {a.x, a.y, a.z, 1.0f}; }
+        else qc = ld4(patch_ptr(prm, cx, qid)->coord);
+        const F4 diff = sub4(qc, c.coord);
         hp += norm4(diff);
         tb_stf<G>(rows, 3 * t + 0, dot4(diff, xdir)); tb_stf<G>(rows, 3 * t + 1, dot4(diff, ydir)); tb_stf<G>(rows, 3 * t + 2, dot4(diff, c.normal));
     }
@@ -600,7 +689,8 @@ MVS_CHECK_FN int check_patch(const DParams& prm, const WaveCtx& wc, const CheckC
     if (gain < 0.0f) { c.nimg = 0; return 1; }
     if (MVS_CHECK_STAGES < 2) return 0;
     int* table = reinterpret_cast<int*>(lds);
-    int n = find_neighbors<MVS_HASH_CAP>(prm, wc, cx, c, table, 4.0f, 2);
+    static_assert(MVS_HASH_CAP + 64 <= MVS_CHECK_LDS_FLOATS, "the marks of the row walk sit behind the id set");
+    int n = find_neighbors<MVS_HASH_CAP, false, false, MVS_FN_MARKS != 0>(prm, wc, cx, c, table, 4.0f, 2, nullptr, table + MVS_HASH_CAP);
     if (n < 0 || n > MVS_ROW_CAP) {
         if (!BIG) return -1;
         n = find_neighbors<MVS_FILTER2_HASH_CAP, true>(prm, wc, cx, c, big_table, 4.0f, 2);

@@ -172,6 +172,9 @@ struct mvs_engine {
     bool index_valid = false;
     DevBuf<uint32_t> dirty;      // Filter::run: one bit per depth-map cell whose nearest patch the last stage removed
     bool dirty_marked = false;
+    DevBuf<float4> geo;            // Filter::run: the packed geometry of the pool (DParams::geo), 2 words per patch
+    DevBuf<uint8_t> geo_ref;       //              and the reference views
+    bool geo_valid = false;        // between pack_geometry and the end of that Filter::run
     bool lists_dense[2] = {false, false};  // m_pgrids / m_vpgrids index built without the trim: the lists of neighbouring cells lie end to end
     // sweep / staging
     DevBuf<DPatch> staging;
@@ -310,6 +313,8 @@ DParams current_params(mvs_engine* e) {
     p.csr_start = e->start.p; p.csr_cnt = e->cnt_alive.p; p.csr_key = e->key.p; p.csr_id32 = e->id32.p;
     p.vcsr_start = e->vstart.p; p.vcsr_cnt = e->vcnt_alive.p; p.vcsr_id32 = e->vid32.p;
     p.dpgrid = e->dpgrid.p;
+    p.geo = e->geo_valid ? e->geo.p : nullptr;
+    p.geo_ref = e->geo_valid ? e->geo_ref.p : nullptr;
     return p;
 }
 
@@ -573,6 +578,29 @@ int rebuild_tail(mvs_engine* e, bool need_vpgrid) {
     HIPCHK(hipGetLastError());
     return MVS_OK;
 }
+// Filter::run never moves a patch, so what its stages read of the patches they MEET -- position, normal, depth scale, score, and (in
+// filterOutside, before filterExact picks reference views anew) the reference view -- is packed once per call: 32 bytes + 1 per patch
+// instead of a 96-byte record (192 in the 64-view build) that straddles cache lines.  filterNeighbor met ~40 KB of records per patch and ran at
+// the HBM rate (5.7 TB/s, profiles/r04_pmc_traffic_per_kernel_filter_run.csv).  A pool with a record whose coord.w / normal.w are not
+// 1 / 0 (only a caller's own seeds can be), or no memory for the copy: the stages read the records, as they did.
+int pack_geometry(mvs_engine* e) {
+    e->geo_valid = false;
+    if (e->pool_n <= 0) return MVS_OK;
+#ifdef MVS_FAULT_INJECTION  // test builds only: MVS_FAULT_NOPACK=1 keeps Filter::run on the records, so a test can compare the two paths
+    if (const char* f = getenv("MVS_FAULT_NOPACK")) { if (atoi(f)) return MVS_OK; }
+#endif
+    if (e->geo.ensure(2 * e->pool_n) != MVS_OK || e->geo_ref.ensure(e->pool_n) != MVS_OK) { (void)hipGetLastError(); return MVS_OK; }
+    hipStream_t st = e->stream;
+    int32_t* bad = reinterpret_cast<int32_t*>(e->misc.p + 5);
+    HIPCHK(hipMemsetAsync(bad, 0, sizeof(unsigned long long), st));
+    mvsk_geo_pack(e->pool.p, e->pool_n, e->geo.p, e->geo_ref.p, bad, st);
+    int32_t hbad = 1;
+    HIPCHK(hipMemcpyAsync(&hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    e->geo_valid = hbad == 0;
+    return MVS_OK;
+}
 // returns != 0 when the call is given up (all ranks alike)
 int filter_rebuild(FilterRun& fr, int additive, bool need_pgrid, bool need_vpgrid, int incr = 0) {
     FR(rebuild_head(fr.e, additive, need_pgrid, incr));
@@ -809,6 +837,7 @@ int mvs_engine_set_views(mvs_engine* e, int nviews, const mvs_view_desc* views) 
         }
     }
     e->ids.headroom = e->key.headroom = e->id32.headroom = e->id32_raw.headroom = e->vid32.headroom = true;
+    e->geo.headroom = e->geo_ref.headroom = true;
     if (e->pool.ensure(pool_cap) || e->pool_alt.ensure(pool_cap) || e->kill.ensure(pool_cap) || e->kill_cnt.ensure(pool_cap + 2) || e->kill_base.ensure(pool_cap + 2)) return MVS_ERR_HIP;
     HIPCHK(hipMemsetAsync(e->kill.p, 0, (size_t)pool_cap, st));
     // jobs of one colour pass over every view (upper bound, used to size the staging bookkeeping)
@@ -1372,8 +1401,8 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     FRHIP(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
     if (e->pool_n > 0) FRHIP(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));
     e->fstats = mvs_filter_stats{};
-    FR(e->fstat_buf.ensure(4096));
-    FRHIP(hipMemsetAsync(e->fstat_buf.p, 0, 4096 * sizeof(unsigned long long), st));
+    FR(e->fstat_buf.ensure(4096 + 16));  // [4096..]: k_filter_neighbor's stage cycles (-DMVS_STAGE_TIMING)
+    FRHIP(hipMemsetAsync(e->fstat_buf.p, 0, (4096 + 16) * sizeof(unsigned long long), st));
     FR(mvs_engine_num_patches(e, &e->fstats.patches_in));
     e->fstats_exchange_bytes = 0;
     int64_t first = 0, last = 0;  // this rank's share of the pool (everything on one GPU)
@@ -1381,6 +1410,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     // every `break` below: the ranks have agreed to give the call up (or, on one GPU, a step failed)
     do {
         if (filter_rebuild(fr, 0, true, false)) break;
+        FR(pack_geometry(e));
         FRHIP(hipEventRecord(e->fev[0], st));
         filter_range(e, first, last);
         if (fr.live()) mvsk_filter_outside(current_params(e), e->kill.p, first, last, st);          // filterOutside
@@ -1437,6 +1467,16 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
             if (fr.live()) mvsk_filter_neighbor_retry(current_params(e), e->kill.p, e->uf_parent.p, nr, e->error_flag.p, e->fstat_buf.p, st);
             FRHIP(hipGetLastError());  // a refused launch (LDS request) must not pass for "nothing to filter"
             FRHIP(hipEventRecord(e->fev[5], st));
+#ifdef MVS_STAGE_TIMING
+            if (fr.live()) {
+                unsigned long long hc[16] = {0};
+                (void)hipMemcpyAsync(hc, e->fstat_buf.p + 4096, sizeof hc, hipMemcpyDeviceToHost, st);
+                (void)hipStreamSynchronize(st);
+                const double w = (double)(hc[0] ? hc[0] : 1);
+                fprintf(stderr, "[filterNeighbor cycles] load + grids %.1f%% set build %.1f%% gather + predicate %.1f%% filterQuad %.1f%% (wave cycles %.3e)\n",
+                        100.0 * hc[1] / w, 100.0 * hc[9] / w, 100.0 * hc[10] / w, 100.0 * hc[11] / w, (double)hc[0]);
+            }
+#endif
         }
         filter_fault_point(fr, 3);
         if (filter_exchange(fr, true, false)) break;
@@ -1472,6 +1512,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     } while (0);
     const int status = filter_agree(fr);  // the closing agreement (one GPU: this rank's own status)
     e->index_valid = false;
+    e->geo_valid = false;  // compact_pool renumbers the patches
     if (status != MVS_OK) {
         // given up: what the unfinished stage marked is forgotten.  The stages that completed stand (on every rank alike); a stage that
         // was under way may have rewritten the lists of this rank's share only -- after an error the caller re-uploads or stops.

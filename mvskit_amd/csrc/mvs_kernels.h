@@ -37,6 +37,7 @@ void mvsk_append_records(DPatch* pool, int64_t pool_n, const DPatch* recs, int64
 void mvsk_alive_count(const DPatch* pool, int64_t n, int32_t* cnt, hipStream_t st);
 void mvsk_alive_gather(const DPatch* pool, int64_t n, const int32_t* base, DPatch* out, int64_t cap, hipStream_t st);
 void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_t last, const uint32_t* dirty, hipStream_t st);
+void mvsk_geo_pack(const DPatch* pool, int64_t n, float4* geo, uint8_t* ref, int* bad, hipStream_t st);
 void mvsk_filter_outside(const DParams& prm, uint8_t* kill, int64_t first, int64_t last, hipStream_t st);
 void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* evals, unsigned long long* stage, int64_t first, int64_t last, hipStream_t st);
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, int64_t first, int64_t last, hipStream_t st);

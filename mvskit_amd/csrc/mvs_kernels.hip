@@ -781,7 +781,8 @@ __global__ __launch_bounds__(64) void k_filter_vimages(DParams prm, int additive
 __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kill, int64_t first) {
     __shared__ int s_dummy[1];
     __shared__ int s_gain[MVS_LISTCAP];
-    const DPatch* p = prm.pool + first + blockIdx.x;
+    const int64_t pid = first + (int64_t)blockIdx.x;
+    const DPatch* p = prm.pool + pid;
     if (!(p->flags & 1)) return;
     WaveCtx wc = make_wave_ctx(prm);
     Cand c;
@@ -789,8 +790,20 @@ __global__ __launch_bounds__(64) void k_filter_outside(DParams prm, uint8_t* kil
     set_grids(prm, wc, c);
     set_vgrids(prm, wc, c);
     const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, nullptr};
-    const float gain = compute_gain(prm, wc, cx, c, s_gain);
-    if (wc.lane == 0 && gain < 0.0f) kill[first + blockIdx.x] = 1;
+    const float gain = prm.geo ? compute_gain<true>(prm, wc, cx, c, s_gain) : compute_gain<false>(prm, wc, cx, c, s_gain);
+    if (wc.lane == 0 && gain < 0.0f) kill[pid] = 1;
+}
+// The packed geometry of Filter::run's stages (DParams::geo, geo_ref): a lane per pool record.  *bad becomes 1 when an alive record's
+// coord.w is not 1 or its normal.w not 0 -- the packed form leaves them out, so the stages then read the records as before.
+__global__ void k_geo_pack(const DPatch* pool, int64_t n, float4* geo, uint8_t* ref, int* bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DPatch* p = pool + i;
+    const F4 c = ld4(p->coord), nr = ld4(p->normal);
+    geo[2 * i] = make_float4(c.x, c.y, c.z, p->dscale);
+    geo[2 * i + 1] = make_float4(nr.x, nr.y, nr.z, p->ncc);
+    ref[i] = p->images[0];
+    if ((p->flags & 1) && !(c.w == 1.0f && nr.w == 0.0f)) *bad = 1;
 }
 // Filter::filterExact, filter.cpp:148-263.
 // Visibility phase (filterExactSub: PatchManager::isVisible in the patch's cell and its four neighbours, per view of
@@ -939,23 +952,45 @@ __global__ __launch_bounds__(64) void k_filter_neighbor(DParams prm, uint8_t* ki
     const DPatch* p = prm.pool + id;
     if (!(p->flags & 1)) return;
     WaveCtx wc = make_wave_ctx(prm);
+#ifdef MVS_STAGE_TIMING  // wave cycles: stats[4096 + k], k = 0 whole wave, 1 load + grids, 9 / 10 findNeighbors' two phases, 11 filterQuad
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = CK_NOW();
+    auto st_flush = [&]() { st_acc[0] = CK_NOW() - st_begin; if (wc.lane == 0) for (int k = 0; k < 12; ++k) if (st_acc[k]) atomicAdd(stats + 4096 + k, st_acc[k]); };
+#endif
     Cand c;
     load_cand(p, wc, c);
     set_grids(prm, wc, c);
+#ifdef MVS_STAGE_TIMING
+    const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, st_acc};
+    st_acc[1] = CK_NOW() - st_begin;
+#else
     const CheckCtx cx{prm.pool, -1, -1, 0, s_dummy, nullptr};
+#endif
     int* table = reinterpret_cast<int*>(s_lds);
     unsigned st4[4] = {0u, 0u, 0u, 0u};
-    const int n = find_neighbors<HCAP, false>(prm, wc, cx, c, table, 4.0f, 2, st4);
+    const bool pk = prm.geo != nullptr;
+    // the first launch keeps the marks of the row walk behind its set (64 dwords more than the set needs); the second launch's table
+    // fills the 64 KB a block may have, and it walks its rows by the binary search
+    constexpr bool MK = MVS_FN_MARKS != 0 && HCAP == MVS_FILTER_HASH_CAP;
+    int* const marks = reinterpret_cast<int*>(s_lds) + MVS_SET_LDS_FLOATS(HCAP, RCAP);
+    const int n = pk ? find_neighbors<HCAP, false, true, MK>(prm, wc, cx, c, table, 4.0f, 2, st4, marks) : find_neighbors<HCAP, false, false, MK>(prm, wc, cx, c, table, 4.0f, 2, st4, marks);
     if (n < 0 || n > RCAP) {
         if (wc.lane == 0) {
             if (retry) retry[atomicAdd(nretry, 1)] = (int32_t)id;
             else atomicOr(overflow, 4);
         }
+#ifdef MVS_STAGE_TIMING
+        st_flush();
+#endif
         return;
     }
     if (wc.lane < 4) atomicAdd(stats + 4 * (blockIdx.x & 1023u) + wc.lane, (unsigned long long)(wc.lane == 0 ? st4[0] : wc.lane == 1 ? st4[1] : wc.lane == 2 ? st4[2] : st4[3]));
-    const bool reject = n < 6 || filter_quad(prm, wc, cx, c, table, n, s_lds + rows_offset(n)) != 0;
+    const bool reject = n < 6 || (pk ? filter_quad<false, true>(prm, wc, cx, c, table, n, s_lds + rows_offset(n)) : filter_quad<false, false>(prm, wc, cx, c, table, n, s_lds + rows_offset(n))) != 0;
     if (wc.lane == 0 && reject) kill[id] = 1;
+#ifdef MVS_STAGE_TIMING
+    st_acc[11] = CK_NOW() - st_begin - st_acc[1] - st_acc[9] - st_acc[10];
+    st_flush();
+#endif
 }
 // Filter::filterSmallGroups, filter.cpp:432-578, as connected components of the symmetrised relation: lock-free
 // union-find, the smaller id becomes the root.
@@ -1262,6 +1297,10 @@ void mvsk_filter_vimages(const DParams& prm, int additive, int64_t first, int64_
     else if (gl == 32) hipLaunchKernelGGL(k_filter_vimages<32>, dim3(nb), dim3(64), 0, st, prm, additive, first, last, dirty);
     else hipLaunchKernelGGL(k_filter_vimages<64>, dim3(nb), dim3(64), 0, st, prm, additive, first, last, dirty);
 }
+void mvsk_geo_pack(const DPatch* pool, int64_t n, float4* geo, uint8_t* ref, int* bad, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_geo_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pool, n, geo, ref, bad);
+}
 void mvsk_filter_outside(const DParams& prm, uint8_t* kill, int64_t first, int64_t last, hipStream_t st) {
     if (last > first) hipLaunchKernelGGL(k_filter_outside, dim3((unsigned)(last - first)), dim3(64), 0, st, prm, kill, first);
 }
@@ -1283,7 +1322,7 @@ void mvsk_filter_exact(const DParams& prm, uint8_t* kill, unsigned long long* ev
 void mvsk_filter_neighbor(const DParams& prm, uint8_t* kill, int32_t* retry, int32_t* nretry, int32_t* overflow, unsigned long long* stats, int64_t first, int64_t last, hipStream_t st) {
     if (last <= first) return;
     hipLaunchKernelGGL((k_filter_neighbor<MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP>), dim3((unsigned)(last - first)), dim3(64),
-                       (size_t)MVS_SET_LDS_FLOATS(MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP) * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow, stats, first);
+                       (size_t)(MVS_SET_LDS_FLOATS(MVS_FILTER_HASH_CAP, MVS_FILTER_ROW_CAP) + 64) * sizeof(float), st, prm, kill, (const int32_t*)nullptr, 0, retry, nretry, overflow, stats, first);
 }
 void mvsk_filter_neighbor_retry(const DParams& prm, uint8_t* kill, const int32_t* todo, int32_t ntodo, int32_t* overflow, unsigned long long* stats, hipStream_t st) {
     if (ntodo <= 0) return;

@@ -86,6 +86,11 @@ struct DParams {
     const csr_off_t* vcsr_start;
     const int32_t* vcsr_cnt;
     const int32_t* vcsr_id32;
+    // Inside Filter::run only (else null): the geometry the neighbour predicates read of a listed patch, packed to 32 bytes -- two
+    // 16-byte words per patch, (coord.xyz, m_dscale) and (normal.xyz, m_ncc) -- and its reference view as a byte: one 32-byte sector per
+    // patch met instead of two or three cache lines of its record (k_geo_pack; only when every coord.w is 1 and every normal.w is 0).
+    const float4* geo;
+    const uint8_t* geo_ref;
     const unsigned long long* dpgrid;  // (sortable depth << 32 | id), ~0ull = m_MAXDEPTH
 };
 

@@ -22,3 +22,17 @@ def test_rcp_and_div_return_the_ieee_quotient(tmp_path):
     print(r.stdout)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     assert "4043309056 inputs" in r.stdout and ", 0 differ from 1.0f / x" in r.stdout
+
+
+@pytest.mark.gpu
+def test_run_lookup_by_marks_is_the_search(tmp_path):
+    """findNeighbors' row walk (mvs_check.cuh, MK): the run an id belongs to comes from marks and four DPP running maxima instead of
+    a binary search per id.  tools/microbench/run_lookup.hip runs both on 65536 waves of 64 runs of random lengths (empty runs, runs
+    longer than the 256-position window) and counts the positions that differ."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "run_lookup")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-Wno-unused-result", "-o", exe,
+                           os.path.join(ROOT, "tools", "microbench", "run_lookup.hip")], stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert r.returncode == 0 and "PASS" in r.stdout and " 0 positions differ" in r.stdout, r.stdout + r.stderr

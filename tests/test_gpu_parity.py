@@ -436,6 +436,38 @@ def test_filter_run_matches_oracle(small_multi_scene):
     np.testing.assert_array_equal(po["vimages"], pe["vimages"])
 
 
+def test_filter_packed_geometry_gives_what_the_records_give(small_multi_scene, monkeypatch):
+    """Inside Filter::run the stages read the patches they meet from a 32-byte packed copy (DParams::geo, mvs_engine.cpp pack_geometry)
+    instead of the records.  The fault-injection build can switch the copy off (MVS_FAULT_NOPACK): both ways the same removals and the
+    same pool, byte for byte, as the oracle's.  A pool with a seed whose coord.w is not 1 cannot be packed (the copy leaves w out): the
+    engine must notice and read the records."""
+    from mvskit_amd import build
+    sc = small_multi_scene
+    monkeypatch.setenv("MVS_ENGINE_LIB", build.FAULT_LIB_PATH)
+    seeds = synth.make_seeds(sc, stride=3, seed=19)
+    odd = seeds.copy()
+    odd["coord"][::7, 3] = 1.0009765625  # homogeneous coordinates the reference would take as they are
+    for variant, sd in (("packed", seeds), ("records", seeds), ("odd w", odd)):
+        monkeypatch.setenv("MVS_FAULT_NOPACK", "1" if variant == "records" else "0")
+        o, e = _pair(sc, seed=21, enable_check=1)
+        o.add_patches(sd)
+        e.upload_patches(sd)
+        for it in range(2):
+            co, ce = o.propagate(it), e.propagate(it)
+            assert co == ce, (variant, it, co, ce)
+            fo, fe = o.filter(), e.filter()
+            assert fo == fe, (variant, it, fo, fe)
+            po, pe = o.patches(), e.patches()
+            np.testing.assert_array_equal(po["images"], pe["images"])
+            np.testing.assert_array_equal(po["vimages"], pe["vimages"])
+            np.testing.assert_allclose(pe["coord"], po["coord"], rtol=REL_TOL, atol=1e-6)
+            o.update_threshold()
+            e.update_threshold()
+        assert fo["neighbor"] + fo["outside"] > 0
+        o.close()
+        e.close()
+
+
 def test_reserve_sizes_the_indexes_up_front(small_multi_scene):
     """mvs_engine_reserve: the cell indexes allocated once (default: MAX_NUM_OF_PATCHES entries per cell) -- the iterations that
     follow compute what they compute without it (two iterations with Optim::check and Filter::run against the oracle), a smaller
