@@ -1431,9 +1431,9 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
             DCounters hc;
             (void)hipMemcpyAsync(&hc, e->counters.p, sizeof hc, hipMemcpyDeviceToHost, st);
             (void)hipStreamSynchronize(st);
-            static const char* nm[7] = {"wave", "frames", "sampling", "pair sums", "choice", "load", "visibility"};
+            static const char* nm[8] = {"wave", "frames", "sampling", "pair sums", "choice", "load", "visibility", "lists"};
             fprintf(stderr, "[filterExact cycles]");
-            for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hc.stage[k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hc.stage[k] / (double)(hc.stage[0] ? hc.stage[0] : 1));
             fprintf(stderr, " (wave cycles %.3e)\n", (double)hc.stage[0]);
         }
 #else

@@ -886,6 +886,7 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
             fpre = make_frame(prm, coord, px, py, normal, image, safe);
         }
     }
+    WC_ADD(wc, 1)
     for (int g = 0; g < MVS_FE_PATCHES; ++g) {
         if (!((alive_b >> ((MVS_FE_LANES * g) & 63)) & 1ull)) continue;
         DPatch* p = prm.pool + (first + (int64_t)blockIdx.x * MVS_FE_PATCHES + g);
@@ -924,9 +925,11 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
                 f.img_lo = (unsigned)__shfl((int)fpre.img_lo, src); f.img_hi = (unsigned)__shfl((int)fpre.img_hi, src);
                 if (!mine) { f.tlx = f.tly = f.dxx = f.dxy = f.dyx = f.dyy = 0.0f; f.ok = 0; }
             }
+            WC_ADD(wc, 7)
             set_ref_image(prm, wc, s_texs, tstride, c, nullptr, &f);  // a patch that gets here made the wave compute fpre
             store_lists(p, wc, c);
             if (wc.lane == 0) p->flags = pflags | MVS_FLAG_SETTLED;
+            WC_ADD(wc, 7)
         } else {
             if (wc.lane == 0) kill[first + (int64_t)blockIdx.x * MVS_FE_PATCHES + g] = 1;
         }
