@@ -614,6 +614,15 @@ def test_check_decisions_second_reading(world):
             rec["coord"][:3] += rec["normal"][:3] * F(rng.uniform(2.0, 12.0) * max(float(rec["dscale"]), 1e-4))
         if k % 4 == 2:
             rec["ncc"] = F(rec["ncc"] - rng.uniform(0.05, 0.3))
+        # a probe pushed off its surface near the border of a view may project outside that view's grid: computeGain indexes
+        # m_pgrids[image][iy * gwidth + ix] with no range test (filter.cpp:108-146; a real patch's m_vgrids are inside by construction,
+        # patch_manager.cpp:284-333), so such a record is not an input the reference is defined on -- and the oracle reads where it does
+        inside = True
+        for v in list(lists_of(rec)[0]) + list(lists_of(rec)[1]):
+            ix, iy = cell_of(cams[v], rec["coord"].astype(F))
+            inside &= 0 <= ix < gdims[v][0] and 0 <= iy < gdims[v][1]
+        if not inside:
+            continue
         f_o, _ = w["o"].check(rec)
         f_r, gain, res = ref_check(cams, gdims, pgrids, vpgrids, patches, rec, w["ncc_thr"])
         if res is not None and abs(res - 2.5) < 0.02:
