@@ -526,7 +526,7 @@ def main():
             # Filter::run (filter.cpp:25-49) -- algorithmic bytes per DESIGN.md "Filter::run": what the two heavy stages have to
             # read and write if every datum moves once
             ex_bytes = f["exact_patches"] * (128 + 72) + f["exact_view_evals"] * (5 * (8 + 16) + ALG_BYTES_PER_VIEW_EVAL)
-            nb_bytes = f["neighbor_patches"] * 128 + f["neighbor_tasks"] * 8 + f["neighbor_entries"] * 4 + f["neighbor_visited"] * 48 + f["neighbor_accepted"] * 32
+            nb_bytes = f["neighbor_patches"] * 128 + f["neighbor_tasks"] * 8 + f["neighbor_entries"] * 4 + f["neighbor_visited"] * 32 + f["neighbor_accepted"] * 16
 
             def blk(ms, nbytes, units, unit_name):
                 gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -541,7 +541,7 @@ def main():
                 "counts": {k: f[k] for k in ("patches_in", "exact_view_evals", "neighbor_tasks", "neighbor_entries", "neighbor_visited", "neighbor_accepted", "neighbor_retried")},
                 "note": "per stage: HIP-event time of its kernel(s) summed over the calls; bytes = record (128 B) + per surviving view 5 depth-map cells "
                         "(8 B) with the patch each names (16 B) + 588 B of setRefImage samples + 72 B of lists written (filterExact); record + 8 B per "
-                        "list opened + 4 B per id walked + 48 B per distinct patch met + 32 B per neighbour fitted (filterNeighbor)"}
+                        "list opened + 4 B per id walked + 32 B per distinct patch met (its packed geometry) + 16 B per neighbour fitted (filterNeighbor)"}
 
         if fstats:
             out["roofline_filter"] = filter_roofline(fstats, args.steps)
