@@ -179,7 +179,7 @@ struct mvs_engine {
     // sweep / staging
     DevBuf<DPatch> staging;
     DevBuf<int32_t> job_stage, job_nstage, job_cnt, job_base_scan, kill_cnt, kill_base, per_view;
-    DevBuf<unsigned long long> misc;  // [0] stage_counter, [1..2] fill_ncc evals, [3] trimmed
+    DevBuf<unsigned long long> misc;  // [0] stage_counter, [1..2] fill_ncc evals, [4..7] small counters of the stages, [8..264) the trim's count in 256 parts
     DevBuf<DCounters> counters;
     DevBuf<int32_t> error_flag;
     DevBuf<int32_t> big_tables, retry_jobs;  // Optim::check's second tier (k_sweep_retry): 256 id sets of 16384 ints, the cells to run again
@@ -334,11 +334,13 @@ int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
     DevBuf<int32_t>& id32 = vgrid ? e->vid32 : e->id32;
     DevBuf<int32_t>& cnt_alive = vgrid ? e->vcnt_alive : e->cnt_alive;
     HIPCHK(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
-    HIPCHK(hipMemsetAsync(e->misc.p + 6, 0, sizeof(unsigned long long), st));
-    mvsk_index_count(p, vgrid ? nullptr : cnt.p, vgrid ? cnt.p : nullptr, e->misc.p + 6, st);
-    mvsk_exclusive_scan_off(cnt.p, start.p, nc, reinterpret_cast<csr_off_t*>(e->scan_tmp.p), st);
-    unsigned long long tot64 = 0;
-    HIPCHK(hipMemcpyAsync(&tot64, e->misc.p + 6, sizeof tot64, hipMemcpyDeviceToHost, st));
+    mvsk_index_count(p, vgrid ? nullptr : cnt.p, vgrid ? cnt.p : nullptr, nullptr, st);
+    const bool direct = unordered && !trim;
+    DevBuf<csr_off_t>& raw = e->start_raw;  // the offsets before the trim (ordered lists): the scan writes them where the sort wants them
+    csr_off_t* const first_scan = direct ? start.p : raw.p;
+    mvsk_exclusive_scan_off(cnt.p, first_scan, nc, reinterpret_cast<csr_off_t*>(e->scan_tmp.p), st);
+    csr_off_t tot64 = 0;  // the number of memberships = the scan's last element (a per-wave atomicAdd to one counter cost the count a third of its time)
+    HIPCHK(hipMemcpyAsync(&tot64, first_scan + nc, sizeof tot64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const int64_t tot = (int64_t)tot64;
     if (!unordered) { if (int r = ids.ensure(tot + 16)) return r; }
@@ -346,19 +348,18 @@ int build_list(mvs_engine* e, bool vgrid, bool trim, bool unordered = false) {
     if (int r = id32.ensure(tot + 16)) return r;
     p = current_params(e);
     HIPCHK(hipMemsetAsync(cursor.p, 0, (size_t)(nc + 1) * sizeof(int32_t), st));
-    if (unordered && !trim) {
+    if (direct) {
         mvsk_index_fill_direct(p, vgrid ? 1 : 0, start.p, cursor.p, id32.p, st);
-        HIPCHK(hipMemcpyAsync(cnt_alive.p, cnt.p, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        std::swap(cnt.p, cnt_alive.p);  // every entry is alive: the counts ARE the alive counts (two buffers of one size; the next build clears its own)
+        std::swap(cnt.cap, cnt_alive.cap);
         e->lists_dense[vgrid ? 1 : 0] = true;
         return MVS_OK;
     }
     // sorted lists [and the trim]: keys -> per-cell sort -> [trim] -> each list's alive entries to the front of its range -> the lists
     // packed end to end (a second scan, over the alive counts), so that every index the engine builds is dense
     if (int r = e->id32_raw.ensure(tot + 16)) return r;
-    DevBuf<csr_off_t>& raw = e->start_raw;
-    HIPCHK(hipMemcpyAsync(raw.p, start.p, (size_t)(nc + 1) * sizeof(csr_off_t), hipMemcpyDeviceToDevice, st));
     mvsk_index_fill(p, vgrid ? 1 : 0, raw.p, cursor.p, ids.p, st);
-    mvsk_index_sort_trim(p, raw.p, ids.p, trim ? 1 : 0, e->misc.p + 3, st);
+    mvsk_index_sort_trim(p, raw.p, ids.p, trim ? 1 : 0, e->misc.p + 8, st);  // [8 .. 264): the trim's count as 256 partial sums
     mvsk_index_finalize(p, vgrid ? 1 : 0, raw.p, ids.p, e->id32_raw.p, cnt_alive.p, st);
     mvsk_exclusive_scan_off(cnt_alive.p, start.p, nc, reinterpret_cast<csr_off_t*>(e->scan_tmp.p), st);
     mvsk_index_pack(p, raw.p, start.p, cnt_alive.p, ids.p, e->id32_raw.p, vgrid ? nullptr : e->key.p, id32.p, st);
@@ -377,6 +378,7 @@ int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
     hipStream_t st = e->stream;
     const DParams p = current_params(e);
     HIPCHK(hipMemsetAsync(e->misc.p + 1, 0, 3 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(e->misc.p + 8, 0, 256 * sizeof(unsigned long long), st));
     // PatchManager::sortPatches re-scores every patch whose m_ncc < 0 each time it meets it
     // (patch_manager.cpp:411-415); a wave that finds m_ncc >= 0 exits at once.
     mvsk_fill_ncc(p, e->misc.p + 1, st);
@@ -386,8 +388,11 @@ int build_index(mvs_engine* e, unsigned long long* trimmed_out) {
     if (want_vgrid(e)) if (int r = build_list(e, true, false, true)) return r;
     if (int r = build_depth(e)) return r;
     if (trimmed_out) {
-        HIPCHK(hipMemcpyAsync(trimmed_out, e->misc.p + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        unsigned long long part[256];
+        HIPCHK(hipMemcpyAsync(part, e->misc.p + 8, sizeof part, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        *trimmed_out = 0;
+        for (unsigned long long v : part) *trimmed_out += v;
     }
     HIPCHK(hipGetLastError());
     e->index_valid = true;
@@ -730,8 +735,8 @@ int mvs_engine_create(const mvs_config* cfg, mvs_engine** out) {
     if (he != hipSuccess) { g_err = std::string("hipStreamCreate: ") + hipGetErrorString(he); delete e; return MVS_ERR_HIP; }
     for (auto& ev : e->ev) (void)hipEventCreate(&ev);
     for (auto& ev : e->fev) (void)hipEventCreate(&ev);
-    if (e->misc.ensure(8) || e->counters.ensure(1) || e->error_flag.ensure(1)) { delete e; return MVS_ERR_HIP; }
-    (void)hipMemset(e->misc.p, 0, 8 * sizeof(unsigned long long));
+    if (e->misc.ensure(8 + 256) || e->counters.ensure(MVS_COUNTER_SLOTS) || e->error_flag.ensure(1)) { delete e; return MVS_ERR_HIP; }
+    (void)hipMemset(e->misc.p, 0, (8 + 256) * sizeof(unsigned long long));
     (void)hipMemset(e->error_flag.p, 0, sizeof(int32_t));
     *out = e;
     return MVS_OK;
@@ -743,6 +748,7 @@ int mvs_engine_destroy(mvs_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     (void)mvs_engine_comm_release(e);
     e->comm_counts.release(); e->comm_kill_ids.release();
+    e->geo.release(); e->geo_ref.release();
     free_views(e);
     e->dviews.release(); e->pool.release(); e->pool_alt.release(); e->kill.release();
     e->cnt.release(); e->start.release(); e->cursor.release(); e->ids.release(); e->vcnt.release(); e->vstart.release();
@@ -1072,7 +1078,7 @@ static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     a.big_tables = e->big_tables.p; a.retry_jobs = e->retry_jobs.p; a.nretry = reinterpret_cast<int32_t*>(e->misc.p + 5);
     HIPCHK(hipMemsetAsync(e->misc.p + 5, 0, sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(e->misc.p, 0, sizeof(unsigned long long), st));
-    HIPCHK(hipMemsetAsync(e->counters.p, 0, sizeof(DCounters), st));
+    HIPCHK(hipMemsetAsync(e->counters.p, 0, MVS_COUNTER_SLOTS * sizeof(DCounters), st));
     HIPCHK(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
     const DParams p = current_params(e);
     mvsk_sweep(p, a, st);
@@ -1086,13 +1092,20 @@ static int pass_impl(mvs_engine* e, int iter, int pass, mvs_counters* out) {
     }
     HIPCHK(hipEventRecord(e->ev[2], st));
     DCounters hc;
+    std::vector<DCounters> hcs(MVS_COUNTER_SLOTS);
     int32_t herr = 0;
     unsigned long long fill[2] = {0, 0};  // evaluations spent on seeds whose m_ncc was < 0 (sortPatches)
     HIPCHK(hipMemcpyAsync(fill, e->misc.p + 1, sizeof fill, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&hc, e->counters.p, sizeof hc, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hcs.data(), e->counters.p, hcs.size() * sizeof(DCounters), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&herr, e->error_flag.p, sizeof herr, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
+    memset(&hc, 0, sizeof hc);
+    for (const DCounters& c : hcs) {
+        hc.candidates += c.candidates; hc.prefiltered += c.prefiltered; hc.patches += c.patches; hc.fail0 += c.fail0; hc.fail1 += c.fail1;
+        hc.inserted += c.inserted; hc.replaced += c.replaced; hc.evals += c.evals; hc.view_evals += c.view_evals; hc.trimmed += c.trimmed;
+        for (int k = 0; k < 16; ++k) hc.stage[k] = (k == 12 || k == 13) ? std::max(hc.stage[k], c.stage[k]) : hc.stage[k] + c.stage[k];
+    }
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->timing.index_ms = ms;
     (void)hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->timing.sweep_ms = ms;
@@ -1401,8 +1414,8 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
     FRHIP(hipMemsetAsync(e->error_flag.p, 0, sizeof(int32_t), st));
     if (e->pool_n > 0) FRHIP(hipMemsetAsync(e->kill.p, 0, (size_t)e->pool_n, st));
     e->fstats = mvs_filter_stats{};
-    FR(e->fstat_buf.ensure(4096 + 16));  // [4096..]: k_filter_neighbor's stage cycles (-DMVS_STAGE_TIMING)
-    FRHIP(hipMemsetAsync(e->fstat_buf.p, 0, (4096 + 16) * sizeof(unsigned long long), st));
+    FR(e->fstat_buf.ensure(4096 + 16 + 2048));  // [4096..]: k_filter_neighbor's stage cycles (-DMVS_STAGE_TIMING); [4112..]: k_filter_exact's [1024][2] work counts
+    FRHIP(hipMemsetAsync(e->fstat_buf.p, 0, (4096 + 16 + 2048) * sizeof(unsigned long long), st));
     FR(mvs_engine_num_patches(e, &e->fstats.patches_in));
     e->fstats_exchange_bytes = 0;
     int64_t first = 0, last = 0;  // this rank's share of the pool (everything on one GPU)
@@ -1427,7 +1440,7 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
 #ifdef MVS_STAGE_TIMING
         FRHIP(hipMemsetAsync(e->counters.p, 0, sizeof(DCounters), st));
         if (fr.live()) {
-            mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, e->counters.p->stage, first, last, st);
+            mvsk_filter_exact(current_params(e), e->kill.p, e->fstat_buf.p + 4112, e->counters.p->stage, first, last, st);
             DCounters hc;
             (void)hipMemcpyAsync(&hc, e->counters.p, sizeof hc, hipMemcpyDeviceToHost, st);
             (void)hipStreamSynchronize(st);
@@ -1437,13 +1450,15 @@ int mvs_engine_filter(mvs_engine* e, int64_t* removed4) {  // Filter::run, filte
             fprintf(stderr, " (wave cycles %.3e)\n", (double)hc.stage[0]);
         }
 #else
-        if (fr.live()) mvsk_filter_exact(current_params(e), e->kill.p, e->misc.p + 1, nullptr, first, last, st);  // filterExact
+        if (fr.live()) mvsk_filter_exact(current_params(e), e->kill.p, e->fstat_buf.p + 4112, nullptr, first, last, st);  // filterExact
 #endif
         FRHIP(hipEventRecord(e->fev[3], st));
         {
-            unsigned long long ev2[2] = {0, 0};
-            FRHIP(hipMemcpyAsync(ev2, e->misc.p + 1, sizeof ev2, hipMemcpyDeviceToHost, st));
+            std::vector<unsigned long long> ev(2048, 0ull);
+            FRHIP(hipMemcpyAsync(ev.data(), e->fstat_buf.p + 4112, ev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             FRHIP(hipStreamSynchronize(st));
+            unsigned long long ev2[2] = {0, 0};
+            for (size_t k = 0; k < ev.size(); ++k) ev2[k & 1] += ev[k];
             e->fstats.exact_view_evals = (int64_t)ev2[1];
         }
         filter_fault_point(fr, 1);

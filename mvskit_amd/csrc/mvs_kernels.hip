@@ -145,7 +145,7 @@ __global__ void k_index_count(DParams prm, int32_t* __restrict__ cnt, int32_t* _
         }
     }
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, (unsigned long long)mine);
+    if (total && (threadIdx.x & 63) == 0 && mine) atomicAdd(total, (unsigned long long)mine);  // (the index build reads the sum off its scan instead)
 }
 // one grid per launch (vgrid = 0: m_pgrids from m_images, 1: m_vpgrids from m_vimages): the sort key travels with the id, the per-cell
 // sort reads no patch
@@ -211,9 +211,10 @@ __global__ void k_index_sort_trim(DParams prm, const csr_off_t* __restrict__ sta
             const int old = atomicAnd(&prm.pool[(uint32_t)ids[k]].flags, ~1);
             mine += old & 1;
         }
-        // one counter update per wave, not per trimmed patch (a million same-address atomics cost milliseconds)
+        // one counter update per wave, not per trimmed patch, and into one of 256 partial sums (waves that end on an atomic to ONE
+        // address leave in single file: the host adds the partial sums)
         for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
-        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(trimmed, (unsigned long long)mine);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(trimmed + (blockIdx.x & 255u), (unsigned long long)mine);
     }
 }
 // After the trim: every list is compacted to its alive entries (order kept) at the FRONT of its own range -- the id to id32, the
@@ -600,7 +601,7 @@ DEV void sweep_cell(const DParams& prm, const SweepArgs& a, const int64_t job, i
     }
     if (wc.lane == 0) {
         a.job_nstage[job] = ns;
-        DCounters* C = a.counters;
+        DCounters* C = a.counters + (job & (MVS_COUNTER_SLOTS - 1));  // partial sums, added up by the host: a million waves on ONE cache line queue up
         if (n_cand) atomicAdd(&C->candidates, (unsigned long long)n_cand);
         if (n_pref) atomicAdd(&C->prefiltered, (unsigned long long)n_pref);
         if (n_patch) atomicAdd(&C->patches, (unsigned long long)n_patch);
@@ -934,7 +935,8 @@ __global__ __launch_bounds__(64) void k_filter_exact(DParams prm, uint8_t* kill,
             if (wc.lane == 0) kill[first + (int64_t)blockIdx.x * MVS_FE_PATCHES + g] = 1;
         }
     }
-    if (wc.lane == 0 && wc.evals) { atomicAdd(evals, (unsigned long long)wc.evals); atomicAdd(evals + 1, (unsigned long long)wc.view_evals); }
+    // the two work counts as 1024 partial sums (the host adds them): 1.5 M waves adding to one address queue up behind each other
+    if (wc.lane == 0 && wc.evals) { atomicAdd(evals + 2 * (blockIdx.x & 1023u), (unsigned long long)wc.evals); atomicAdd(evals + 2 * (blockIdx.x & 1023u) + 1, (unsigned long long)wc.view_evals); }
 #ifdef MVS_STAGE_TIMING
     if (stage && wc.lane == 0) {
         atomicAdd(stage, (unsigned long long)__builtin_amdgcn_s_memtime() - fe_begin);
@@ -1106,7 +1108,9 @@ __global__ __launch_bounds__(256) void k_groups_edges(DParams prm, int* parent, 
         if (h1) edge(e1);
     }
 }
-__global__ void k_groups_count(DParams prm, int* parent, int* size) {
+// `sat`: a set's size is only ever compared with the removal threshold, so counting stops there (a plain load first) -- the one giant
+// component drew 94 k adds to one address per call.  INT_MAX where the sizes themselves are used (the literal labelling).
+__global__ void k_groups_count(DParams prm, int* parent, int* size, int sat) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= prm.pool_n || !(prm.pool[id].flags & 1)) return;
     const int r = uf_find(parent, (int)id);
@@ -1114,8 +1118,8 @@ __global__ void k_groups_count(DParams prm, int* parent, int* size) {
     // one giant component holds almost every patch: lanes that share the first active lane's root add once
     const int r0 = __builtin_amdgcn_readfirstlane(r);
     const unsigned long long same = __ballot(r == r0);
-    if (r == r0) { if ((int)(threadIdx.x & 63u) == __ffsll((long long)same) - 1) atomicAdd(&size[r0], (int)__popcll(same)); }
-    else atomicAdd(&size[r], 1);
+    if (r == r0) { if ((int)(threadIdx.x & 63u) == __ffsll((long long)same) - 1 && __atomic_load_n(&size[r0], __ATOMIC_RELAXED) < sat) atomicAdd(&size[r0], (int)__popcll(same)); }
+    else if (__atomic_load_n(&size[r], __ATOMIC_RELAXED) < sat) atomicAdd(&size[r], 1);
 }
 __global__ void k_groups_kill(DParams prm, const int* parent, const int* size, int threshold, uint8_t* kill) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1336,7 +1340,7 @@ void mvsk_groups(const DParams& prm, int* parent, int* size, int threshold, uint
     if (prm.pool_n <= 0) return;
     hipLaunchKernelGGL(k_groups_init, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, parent, size, prm.pool_n);
     hipLaunchKernelGGL(k_groups_edges<0>, dim3(nblk(prm.pool_n, 4)), dim3(256), 0, st, prm, parent, (int2*)nullptr, (int*)nullptr, 0);
-    hipLaunchKernelGGL(k_groups_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size);
+    hipLaunchKernelGGL(k_groups_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size, threshold);
     hipLaunchKernelGGL(k_groups_kill, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size, threshold, kill);
 }
 // the literal labelling in three steps (mvs_engine.cpp does the middle one on the host): sets joined by edges that run both ways and
@@ -1345,7 +1349,7 @@ void mvsk_groups_literal_edges(const DParams& prm, int* parent, int* size, int* 
     if (prm.pool_n <= 0) return;
     hipLaunchKernelGGL(k_groups_init, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, parent, size, prm.pool_n);
     hipLaunchKernelGGL(k_groups_edges<1>, dim3(nblk(prm.pool_n, 4)), dim3(256), 0, st, prm, parent, (int2*)nullptr, (int*)nullptr, 0);
-    hipLaunchKernelGGL(k_groups_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size);  // also flattens parent[] to the roots
+    hipLaunchKernelGGL(k_groups_count, dim3(nblk(prm.pool_n, 256)), dim3(256), 0, st, prm, parent, size, INT_MAX);  // also flattens parent[] to the roots
     hipLaunchKernelGGL(k_groups_edges<2>, dim3(nblk(prm.pool_n, 4)), dim3(256), 0, st, prm, parent, reinterpret_cast<int2*>(edges2), nedges, cap);
 }
 __global__ void k_gather_i32(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int32_t* __restrict__ out, int64_t n) {

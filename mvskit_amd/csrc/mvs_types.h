@@ -94,6 +94,9 @@ struct DParams {
     const unsigned long long* dpgrid;  // (sortable depth << 32 | id), ~0ull = m_MAXDEPTH
 };
 
+#ifndef MVS_COUNTER_SLOTS
+#define MVS_COUNTER_SLOTS 256  // SweepArgs::counters: that many DCounters, job j adds into slot j % MVS_COUNTER_SLOTS
+#endif
 struct DCounters {
     unsigned long long candidates, prefiltered, patches, fail0, fail1, inserted, replaced, evals, view_evals, trimmed;
     // diagnostic build (-DMVS_STAGE_TIMING): wave cycles (s_memtime) per stage of the sweep, summed over waves:
