@@ -155,7 +155,8 @@ int mvs_engine_upload_patches(mvs_engine* e, int64_t n, const mvs_patch* patches
 int mvs_engine_clear_patches(mvs_engine* e);
 /* Optional: sizes the two cell indexes (PatchManager::m_pgrids / m_vpgrids as lists, patch_manager.hpp) for `list_entries` memberships
  * each up front -- 0 = MAX_NUM_OF_PATCHES per cell of every view -- so that the calls below allocate nothing while the lists stay
- * below that.  Without it the buffers grow inside the first iterations of a run. */
+ * below that.  Without it the buffers grow inside the first iterations of a run.  A buffer that the call allocates is written once
+ * (the first use of fresh device memory is slow); a request the buffers already hold changes nothing. */
 int mvs_engine_reserve(mvs_engine* e, int64_t list_entries);
 int mvs_engine_num_patches(mvs_engine* e, int64_t* n_alive);
 int mvs_engine_download_patches(mvs_engine* e, int64_t cap, mvs_patch* out, int64_t* n); /* collectPatches */
