@@ -1,3 +1,8 @@
+#!/bin/bash
+# tools/final_measurements.sh (on a GPU box, after tools/refresh_profiles.sh): the driver's --steps 20 form of the bench line, the 48-view
+# run with Filter::run, two ranks on one GPU over the loopback transport, and the stage shares of the diagnostic builds
+# (mvskit_amd/lib/variant_st{,32,64}.so: tools/build_here.sh st -DMVS_STAGE_TIMING [-DMVS_LISTCAP=32 | -DMVS_LISTCAP=64 -DMVS_MAX_IMAGES=64]),
+# into gpurun_out/r04final/
 set -e
 O=gpurun_out/r04final; mkdir -p $O; L=$PWD/mvskit_amd/lib
 timeout -k 10 600 python bench.py --steps 20 --warmup 2 > $O/r04_bench_1gpu_steps20.json 2> $O/steps20.log
