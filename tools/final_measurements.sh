@@ -5,7 +5,7 @@
 # into gpurun_out/r04final/
 set -e
 O=gpurun_out/r04final; mkdir -p $O; L=$PWD/mvskit_amd/lib
-timeout -k 10 600 python bench.py --steps 20 --warmup 2 > $O/r04_bench_1gpu_steps20.json 2> $O/steps20.log
+timeout -k 10 700 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r04_bench_1gpu_steps20.json 2> $O/steps20.log
 timeout -k 10 300 python bench.py --filter --views 48 --width 960 --height 540 --steps 3 --warmup 1 --cpu-seconds 0 --no-config5 --no-config4 > $O/r04_bench_filter_48x540p.json 2> $O/f48.log
 MVS_CCL_LIBRARY=$PWD/tests/loopback_ccl/_build/libloopback_ccl.so timeout -k 10 400 python bench.py --gpus 2 --steps 3 --warmup 1 --cpu-seconds 0 --no-config5 --no-config4 > $O/r04_bench_2ranks_one_gpu_loopback.json 2> $O/loop.log
 (echo "## 16-view build (12 views 1920x1080)"; MVS_ENGINE_LIB=$L/variant_st.so timeout -k 10 300 python bench.py --filter --steps 3 --warmup 1 --cpu-seconds 0 --no-config5 --no-config4 2>&1 | grep -a "cycles\]"
