@@ -471,7 +471,7 @@ def test_filter_packed_geometry_gives_what_the_records_give(small_multi_scene, m
 def test_reserve_sizes_the_indexes_up_front(small_multi_scene):
     """mvs_engine_reserve: the cell indexes allocated once (default: MAX_NUM_OF_PATCHES entries per cell) -- the iterations that
     follow compute what they compute without it (two iterations with Optim::check and Filter::run against the oracle), a smaller
-    request later changes nothing, a negative one is refused."""
+    request later changes nothing, a larger one between two calls replaces the buffers without harm, a negative one is refused."""
     sc = small_multi_scene
     seeds = synth.make_seeds(sc, stride=3, seed=19)
     o, e = _pair(sc, seed=21, enable_check=1)
@@ -482,6 +482,8 @@ def test_reserve_sizes_the_indexes_up_front(small_multi_scene):
         co, ce = o.propagate(it), e.propagate(it)
         assert co == ce, (it, co, ce)
         e.reserve(1000)
+        if it == 0:
+            e.reserve(40_000_000)  # larger than what the indexes hold: the buffers are replaced (and written once), the lists in them are gone -- the calls that follow must rebuild them
         fo, fe = o.filter(), e.filter()
         assert fo == fe, (it, fo, fe)
         o.update_threshold()
